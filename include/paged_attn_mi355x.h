@@ -1,0 +1,150 @@
+/*
+ * paged_attn_mi355x — C ABI of the MI355X (gfx950) PagedAttention decode path.
+ *
+ * One shared library, libpaged_attn_mi355x.so, replaces the device side of
+ * vLLM v0.1.0's two operator modules:
+ *
+ *   vllm.attention_ops   csrc/attention.cpp:3-19
+ *   vllm.cache_ops       csrc/cache.cpp:6-47
+ *
+ * Every entry point takes plain pointers and sizes (no torch types), launches
+ * its work asynchronously on the HIP stream it is given (NULL = the default
+ * stream) and returns PA_OK or an error code; pa_last_error() then holds a
+ * message for the calling thread.  Nothing is allocated, freed or synchronised
+ * by any entry point, so all of them are safe under HIP graph capture, except
+ * that pa_swap_blocks issues hipMemcpyAsync calls (capturable, but they become
+ * memcpy nodes).  All device pointers must belong to the current HIP device.
+ *
+ * Element types: see pa_dtype.  Cache layouts, with x = 16 / sizeof(element)
+ * (vllm/worker/cache_engine.py:48-63):
+ *
+ *   key_cache    [num_blocks, num_heads, head_size / x, block_size, x]
+ *   value_cache  [num_blocks, num_heads, head_size, block_size]
+ *
+ * All offsets are computed in 64 bits: a cache tensor may hold more than 2^31
+ * elements (the reference's kernels index with 32-bit ints).
+ */
+#ifndef PAGED_ATTN_MI355X_H_
+#define PAGED_ATTN_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+typedef enum pa_dtype {
+  PA_DTYPE_F32 = 0,  /* float                       (at::ScalarType::Float)    */
+  PA_DTYPE_F16 = 1,  /* IEEE binary16               (at::ScalarType::Half)     */
+  PA_DTYPE_BF16 = 2  /* bfloat16                    (at::ScalarType::BFloat16) */
+} pa_dtype;
+
+typedef enum pa_status {
+  PA_OK = 0,
+  PA_ERR_INVALID_ARGUMENT = 1, /* null pointer, negative size, misalignment   */
+  PA_ERR_UNSUPPORTED = 2,      /* dtype / head_size / block_size not built    */
+  PA_ERR_HIP = 3               /* a HIP runtime call or kernel launch failed  */
+} pa_status;
+
+typedef enum pa_copy_kind {
+  PA_COPY_DEVICE_TO_DEVICE = 0,
+  PA_COPY_DEVICE_TO_HOST = 1,
+  PA_COPY_HOST_TO_DEVICE = 2
+} pa_copy_kind;
+
+/* ABI version of the loaded library (== PA_ABI_VERSION it was built with). */
+int pa_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* pa_last_error(void);
+
+/*
+ * Decode attention of one new token per sequence over the paged KV cache.
+ * Replaces single_query_cached_kv_attention
+ * (csrc/attention/attention_kernels.cu:450-469; kernel :67-314).
+ *
+ *   out          [num_seqs, num_heads, head_size], dense
+ *   query        [num_seqs, num_heads, head_size], row stride q_stride elements
+ *                (q is a column slice of the fused qkv projection)
+ *   block_tables [num_seqs, max_num_blocks_per_seq] int32; entries past
+ *                ceil(context_len / block_size) are never read
+ *   context_lens [num_seqs] int32, each >= 0 (0 writes zeros for that row)
+ *
+ * out = softmax(scale * q . K^T) . V per (sequence, head), with the softmax
+ * denominator (sum + 1e-6) of the reference kernel (:213).  Supported:
+ * head_size in {64, 80, 96, 128}, block_size in {8, 16, 32}, all pa_dtype
+ * values — the set the reference instantiates (:370-400, :416-448); anything
+ * else returns PA_ERR_UNSUPPORTED, where the reference raises.
+ * max_context_len is accepted for signature parity and only validated: the
+ * kernel keeps no per-context buffer, so context length is not limited by LDS.
+ */
+int pa_single_query_cached_kv_attention(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    float scale, const int32_t* block_tables, const int32_t* context_lens,
+    int num_seqs, int num_heads, int head_size, int block_size,
+    int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
+    int dtype, void* stream);
+
+/*
+ * Scatter new key/value vectors into the paged caches.
+ * Replaces reshape_and_cache (csrc/cache_kernels.cu:186-224; kernel :143-182).
+ *
+ *   key, value   [num_tokens, num_heads, head_size], row strides in elements
+ *   slot_mapping [num_tokens] int32; slot = block * block_size + offset.
+ *                A negative slot skips the token (the reference has no such
+ *                case; this keeps padded batches from writing out of bounds).
+ */
+int pa_reshape_and_cache(
+    const void* key, const void* value, void* key_cache, void* value_cache,
+    const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int64_t key_stride, int64_t value_stride, int dtype,
+    void* stream);
+
+/*
+ * Inverse of pa_reshape_and_cache: paged caches -> [num_tokens, H, D] rows.
+ * Replaces gather_cached_kv (csrc/cache_kernels.cu:348-386).
+ */
+int pa_gather_cached_kv(
+    void* key, void* value, const void* key_cache, const void* value_cache,
+    const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int block_size, int64_t key_stride, int64_t value_stride, int dtype,
+    void* stream);
+
+/*
+ * For every layer and every (src, dst) pair copy one key block and one value
+ * block inside the same cache tensor.  Replaces copy_blocks
+ * (csrc/cache_kernels.cu:82-138; kernel :53-78).
+ *
+ *   key_cache_ptrs, value_cache_ptrs  HOST arrays of num_layers device pointers
+ *   block_pairs                       HOST array of 2 * num_pairs block numbers
+ *                                     (src0, dst0, src1, dst1, ...)
+ *   block_bytes                       bytes of one block of one cache tensor
+ *
+ * The pointer and pair tables travel in the kernel arguments, so unlike the
+ * reference (three blocking host-to-device copies, :116-121) the call neither
+ * allocates nor synchronises.  The host arrays may be reused as soon as the
+ * call returns.  Pairs are copied concurrently: a block must not be both a
+ * source and a destination in one call.
+ */
+int pa_copy_blocks(
+    void* const* key_cache_ptrs, void* const* value_cache_ptrs, int num_layers,
+    const int64_t* block_pairs, int num_pairs, int64_t block_bytes,
+    void* stream);
+
+/*
+ * Whole-block copies between two different cache tensors (GPU<->GPU on one
+ * device, GPU->pinned host, pinned host->GPU).  Replaces swap_blocks
+ * (csrc/cache_kernels.cu:9-47).  block_pairs as in pa_copy_blocks (HOST).
+ * Runs of consecutive (src, dst) block numbers are merged into one copy.
+ */
+int pa_swap_blocks(
+    const void* src, void* dst, const int64_t* block_pairs, int num_pairs,
+    int64_t block_bytes, int kind, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PAGED_ATTN_MI355X_H_ */

@@ -1,0 +1,275 @@
+"""Deterministic synthetic inputs for the PagedAttention decode path.
+
+TEST INFRASTRUCTURE (used by tests/, oracle/gen_golden.py and smoke()).  The
+generator is a counter-based hash (splitmix64 finaliser over an index), so
+the same (seed, shape) gives the same bits on every numpy version and on
+every machine; golden fixtures therefore only need to store a checksum of the
+inputs plus the expected outputs.
+
+Input conventions follow the reference's kernel tests and its worker:
+  * q is slice 0 of a fused qkv tensor [S, 3, H, D], so its row stride is
+    3*H*D (tests/kernels/test_attention.py:168-171);
+  * key_cache [NB, H, D/x, B, x], value_cache [NB, H, D, B], x = 16/elem size
+    (vllm/worker/cache_engine.py:48-63);
+  * block_tables int32, right-padded with 0 (vllm/worker/worker.py:219-222);
+  * context_len counts the token whose K/V was just written
+    (vllm/worker/worker.py:192).
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+from dataclasses import asdict, dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+DTYPES = ("float32", "float16", "bfloat16")
+DTYPE_CODE = {"float32": 0, "float16": 1, "bfloat16": 2}
+ELEM_SIZE = {"float32": 4, "float16": 2, "bfloat16": 2}
+
+
+def _mix(idx: np.ndarray, seed: int) -> np.ndarray:
+    """splitmix64 finaliser of (idx + seed * golden ratio)."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(n: int, seed: int) -> np.ndarray:
+    """n doubles in [0, 1)."""
+    z = _mix(np.arange(n, dtype=np.uint64), seed)
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform(n: int, seed: int, lo: float, hi: float) -> np.ndarray:
+    return lo + (hi - lo) * uniform01(n, seed)
+
+
+def normal(n: int, seed: int, std: float = 1.0) -> np.ndarray:
+    """Box-Muller on two hashed uniform streams."""
+    u1 = uniform01(n, seed * 2 + 1)
+    u2 = uniform01(n, seed * 2 + 2)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))
+    return std * r * np.cos(2.0 * np.pi * u2)
+
+
+def randint(n: int, seed: int, lo: int, hi: int) -> np.ndarray:
+    """n integers in [lo, hi] (inclusive, like random.randint)."""
+    z = _mix(np.arange(n, dtype=np.uint64), seed)
+    return (lo + (z % np.uint64(hi - lo + 1)).astype(np.int64)).astype(np.int64)
+
+
+def permutation(n: int, seed: int) -> np.ndarray:
+    """A permutation of arange(n): argsort of a hashed key (ties impossible
+    in practice for 64-bit keys; stable sort keeps it deterministic)."""
+    return np.argsort(_mix(np.arange(n, dtype=np.uint64), seed), kind="stable").astype(np.int64)
+
+
+# ---- storage types -------------------------------------------------------
+
+def float_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns, round to nearest even."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    lsb = (u >> np.uint64(16)) & np.uint64(1)
+    r = (u + np.uint64(0x7FFF) + lsb) >> np.uint64(16)
+    return r.astype(np.uint16)
+
+
+def bf16_bits_to_float(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def to_storage(a: np.ndarray, dtype: str) -> np.ndarray:
+    """Round float64 values to the storage type.  bfloat16 is held as uint16
+    bit patterns (numpy has no bfloat16)."""
+    if dtype == "float32":
+        return a.astype(np.float32)
+    if dtype == "float16":
+        return a.astype(np.float32).astype(np.float16)
+    if dtype == "bfloat16":
+        return float_to_bf16_bits(a.astype(np.float32))
+    raise ValueError(dtype)
+
+
+def storage_to_float32(a: np.ndarray, dtype: str) -> np.ndarray:
+    if dtype == "bfloat16":
+        return bf16_bits_to_float(a)
+    return a.astype(np.float32)
+
+
+def storage_to_torch(a: np.ndarray, dtype: str):
+    import torch
+    t = torch.from_numpy(a)
+    if dtype == "bfloat16":
+        t = t.view(torch.bfloat16)
+    return t
+
+
+def torch_to_storage(t, dtype: str) -> np.ndarray:
+    import torch
+    t = t.detach().cpu().contiguous()
+    if dtype == "bfloat16":
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+# ---- decode-attention cases ----------------------------------------------
+
+@dataclass
+class DecodeCase:
+    name: str
+    dtype: str = "float16"
+    num_seqs: int = 5
+    num_heads: int = 3
+    head_size: int = 64
+    block_size: int = 16
+    num_blocks: int = 32
+    # explicit context lengths, or None -> randint(1, max_context) per seq
+    context_lens: Optional[List[int]] = None
+    max_context: int = 64
+    # "uniform1e-3": the reference test's distribution
+    # (tests/kernels/test_attention.py:170,177,181);  "normal": N(0, std)
+    dist: str = "uniform1e-3"
+    std: float = 0.5
+    # "replacement": physical blocks sampled with replacement, as the
+    # reference test does (:190-194); "permutation": all distinct
+    tables: str = "replacement"
+    # extra zero-padded table columns beyond ceil(max_ctx / B)
+    table_pad: int = 0
+    # None -> 1/sqrt(head_size), as the reference test (:197)
+    scale: Optional[float] = None
+    seed: int = 0
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), sort_keys=True)
+
+    @staticmethod
+    def from_json(s: str) -> "DecodeCase":
+        return DecodeCase(**json.loads(s))
+
+
+def _values(n: int, seed: int, case: DecodeCase) -> np.ndarray:
+    if case.dist == "uniform1e-3":
+        return uniform(n, seed, -1e-3, 1e-3)
+    if case.dist == "normal":
+        return normal(n, seed, case.std)
+    raise ValueError(case.dist)
+
+
+def make_decode_inputs(case: DecodeCase) -> Dict[str, object]:
+    """Builds numpy inputs for one decode-attention call.
+
+    Returns a dict with: qkv (storage array [S,3,H,D]; query = qkv[:,0]),
+    key_cache, value_cache (storage arrays), block_tables, context_lens
+    (int32), scale, max_context_len, q_stride.
+    """
+    S, H, D, B, NB = case.num_seqs, case.num_heads, case.head_size, case.block_size, case.num_blocks
+    es = ELEM_SIZE[case.dtype]
+    x = 16 // es
+    assert D % x == 0
+    base = case.seed * 1000
+    qkv = to_storage(_values(S * 3 * H * D, base + 1, case), case.dtype).reshape(S, 3, H, D)
+    kc = to_storage(_values(NB * H * D * B, base + 2, case), case.dtype).reshape(NB, H, D // x, B, x)
+    vc = to_storage(_values(NB * H * D * B, base + 3, case), case.dtype).reshape(NB, H, D, B)
+    if case.context_lens is not None:
+        ctx = np.asarray(case.context_lens, dtype=np.int64)
+        assert ctx.shape == (S,)
+    else:
+        ctx = randint(S, base + 4, 1, case.max_context)
+    max_ctx = int(ctx.max()) if S > 0 else 0
+    nb_max = (max_ctx + B - 1) // B
+    cols = nb_max + case.table_pad
+    tables = np.zeros((S, max(cols, 1)), dtype=np.int32)
+    if case.tables == "replacement":
+        r = randint(S * max(nb_max, 1), base + 5, 0, NB - 1).reshape(S, max(nb_max, 1))
+        for s in range(S):
+            n = (int(ctx[s]) + B - 1) // B
+            tables[s, :n] = r[s, :n]
+    elif case.tables == "permutation":
+        need = int(sum((int(c) + B - 1) // B for c in ctx))
+        assert need <= NB, "permutation tables need num_blocks >= total logical blocks"
+        perm = permutation(NB, base + 5)
+        pos = 0
+        for s in range(S):
+            n = (int(ctx[s]) + B - 1) // B
+            tables[s, :n] = perm[pos:pos + n]
+            pos += n
+    else:
+        raise ValueError(case.tables)
+    scale = float(case.scale) if case.scale is not None else float(1.0 / (D ** 0.5))
+    return {
+        "qkv": qkv,
+        "key_cache": kc,
+        "value_cache": vc,
+        "block_tables": tables,
+        "context_lens": ctx.astype(np.int32),
+        "scale": scale,
+        "max_context_len": max_ctx,
+        "q_stride": 3 * H * D,
+    }
+
+
+def checksum(inputs: Dict[str, object]) -> str:
+    h = hashlib.sha256()
+    for k in ("qkv", "key_cache", "value_cache", "block_tables", "context_lens"):
+        a = np.ascontiguousarray(inputs[k])
+        h.update(k.encode())
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    h.update(repr(float(inputs["scale"])).encode())
+    return h.hexdigest()
+
+
+# ---- cache-op cases -------------------------------------------------------
+
+@dataclass
+class CacheCase:
+    name: str
+    dtype: str = "float16"
+    num_tokens: int = 3
+    num_heads: int = 2
+    head_size: int = 16
+    block_size: int = 8
+    num_blocks: int = 2
+    num_layers: int = 1
+    num_mappings: int = 0
+    seed: int = 0
+    extra: Dict[str, int] = field(default_factory=dict)
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), sort_keys=True)
+
+    @staticmethod
+    def from_json(s: str) -> "CacheCase":
+        return CacheCase(**json.loads(s))
+
+
+def make_cache_inputs(case: CacheCase) -> Dict[str, object]:
+    """Inputs in the shape of tests/kernels/test_cache.py: randn caches (one
+    pair per layer), a qkv tensor whose slices 1 and 2 are key and value,
+    distinct random slots, and disjoint src/dst block lists."""
+    T, H, D, B, NB, L = (case.num_tokens, case.num_heads, case.head_size, case.block_size,
+                         case.num_blocks, case.num_layers)
+    es = ELEM_SIZE[case.dtype]
+    x = 16 // es
+    assert D % x == 0
+    base = case.seed * 1000 + 500
+    qkv = to_storage(normal(max(T, 1) * 3 * H * D, base + 1), case.dtype).reshape(max(T, 1), 3, H, D)[:T]
+    kcs, vcs = [], []
+    for l in range(L):
+        kcs.append(to_storage(normal(NB * H * D * B, base + 10 + 2 * l), case.dtype).reshape(NB, H, D // x, B, x))
+        vcs.append(to_storage(normal(NB * H * D * B, base + 11 + 2 * l), case.dtype).reshape(NB, H, D, B))
+    slots = permutation(NB * B, base + 2)[:T].astype(np.int32)
+    perm = permutation(NB, base + 3)
+    M = case.num_mappings
+    assert 2 * M <= NB
+    src = perm[:M]
+    dst = perm[M:2 * M]
+    return {"qkv": qkv, "key_caches": kcs, "value_caches": vcs, "slot_mapping": slots,
+            "src_blocks": src.astype(np.int64), "dst_blocks": dst.astype(np.int64)}

@@ -1,0 +1,253 @@
+"""GPU parity tests of the cache kernels (bit-exact), driven through the C ABI
+and through the `cache_ops` module."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import datagen, pa_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+CACHE_META, CACHE_DATA = helpers.load_cache_golden()
+DEV = "cuda:0"
+
+
+def _digest(arrs) -> str:
+    h = hashlib.sha256()
+    for a in arrs:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def _to_dev(a, dtype):
+    return datagen.storage_to_torch(np.ascontiguousarray(a).copy(), dtype).to(DEV)
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CACHE_META if n.startswith("reshape")))
+def test_reshape_and_gather_match_reference_fixture(pkg, name):
+    import torch
+    entry = CACHE_META[name]
+    case = helpers.cache_case_from_meta(entry)
+    inp = datagen.make_cache_inputs(case)
+    qkv = _to_dev(inp["qkv"], case.dtype)
+    _, key, value = qkv.unbind(dim=1)
+    kc, vc = _to_dev(inp["key_caches"][0], case.dtype), _to_dev(inp["value_caches"][0], case.dtype)
+    slots = torch.from_numpy(inp["slot_mapping"]).to(DEV)
+    pkg._capi.reshape_and_cache(key, value, kc, vc, slots)
+    torch.cuda.synchronize()
+    assert _digest([datagen.torch_to_storage(kc, case.dtype)]) == entry["reshape_key_cache_sha256"]
+    assert _digest([datagen.torch_to_storage(vc, case.dtype)]) == entry["reshape_value_cache_sha256"]
+    # gather from the ORIGINAL caches into a fresh qkv
+    qkv2 = _to_dev(inp["qkv"], case.dtype)
+    _, key2, value2 = qkv2.unbind(dim=1)
+    kc0, vc0 = _to_dev(inp["key_caches"][0], case.dtype), _to_dev(inp["value_caches"][0], case.dtype)
+    pkg._capi.gather_cached_kv(key2, value2, kc0, vc0, slots)
+    torch.cuda.synchronize()
+    assert _digest([datagen.torch_to_storage(qkv2, case.dtype)]) == entry["gather_qkv_sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CACHE_META if n.startswith("copy")))
+def test_copy_blocks_matches_reference_fixture(pkg, name):
+    import torch
+    entry = CACHE_META[name]
+    case = helpers.cache_case_from_meta(entry)
+    inp = datagen.make_cache_inputs(case)
+    kcs = [_to_dev(a, case.dtype) for a in inp["key_caches"]]
+    vcs = [_to_dev(a, case.dtype) for a in inp["value_caches"]]
+    mapping = {int(s): [int(d)] for s, d in zip(inp["src_blocks"], inp["dst_blocks"])}
+    pkg.cache_ops.copy_blocks(kcs, vcs, mapping)
+    torch.cuda.synchronize()
+    assert _digest(datagen.torch_to_storage(t, case.dtype) for t in kcs) == entry["key_caches_sha256"]
+    assert _digest(datagen.torch_to_storage(t, case.dtype) for t in vcs) == entry["value_caches_sha256"]
+
+
+@pytest.mark.parametrize("dtype", datagen.DTYPES)
+def test_cache_ops_module_like_the_reference_tests(pkg, dtype):
+    """tests/kernels/test_cache.py:66-146 (reshape_and_cache, gather_cached_kv)
+    at the reference's sizes, through the pybind11 module, checked against the
+    oracle bit for bit."""
+    import torch
+    case = datagen.CacheCase(name="ref", dtype=dtype, num_tokens=3, num_heads=2, head_size=16, block_size=8,
+                             num_blocks=2, seed=77)
+    inp = datagen.make_cache_inputs(case)
+    qkv = _to_dev(inp["qkv"], dtype)
+    _, key, value = qkv.unbind(dim=1)
+    kc, vc = _to_dev(inp["key_caches"][0], dtype), _to_dev(inp["value_caches"][0], dtype)
+    slots = torch.from_numpy(inp["slot_mapping"]).to(DEV)
+    pkg.cache_ops.reshape_and_cache(key, value, kc, vc, slots)
+    kc_ref, vc_ref = inp["key_caches"][0].copy(), inp["value_caches"][0].copy()
+    pa_oracle.reshape_and_cache(inp["qkv"][:, 1], inp["qkv"][:, 2], kc_ref, vc_ref, inp["slot_mapping"], dtype)
+    torch.cuda.synchronize()
+    assert np.array_equal(datagen.torch_to_storage(kc, dtype), kc_ref)
+    assert np.array_equal(datagen.torch_to_storage(vc, dtype), vc_ref)
+    # gather back: key/value rows must come back unchanged, query untouched
+    qkv2 = torch.zeros_like(qkv)
+    qkv2[:, 0] = qkv[:, 0]
+    _, k2, v2 = qkv2.unbind(dim=1)
+    pkg.cache_ops.gather_cached_kv(k2, v2, kc, vc, slots)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv2, qkv)
+
+
+@pytest.mark.parametrize("dtype", datagen.DTYPES)
+def test_reshape_and_cache_odd_shapes_and_unaligned_rows(pkg, dtype):
+    import torch
+    case = datagen.CacheCase(name="odd", dtype=dtype, num_tokens=19, num_heads=5, head_size=80, block_size=32,
+                             num_blocks=7, seed=5)
+    inp = datagen.make_cache_inputs(case)
+    T, H, D = case.num_tokens, case.num_heads, case.head_size
+    tdt = datagen.storage_to_torch(inp["qkv"], dtype).dtype
+    # token rows at an odd element offset and an odd row stride -> scalar path
+    stride = H * D + 1
+    kbuf = torch.zeros(T * stride + 1, dtype=tdt, device=DEV)
+    vbuf = torch.zeros(T * stride + 1, dtype=tdt, device=DEV)
+    key = kbuf[1:].as_strided((T, H, D), (stride, D, 1))
+    value = vbuf[1:].as_strided((T, H, D), (stride, D, 1))
+    qkv = _to_dev(inp["qkv"], dtype)
+    key.copy_(qkv[:, 1])
+    value.copy_(qkv[:, 2])
+    kc, vc = _to_dev(inp["key_caches"][0], dtype), _to_dev(inp["value_caches"][0], dtype)
+    slots = torch.from_numpy(inp["slot_mapping"]).to(DEV)
+    pkg._capi.reshape_and_cache(key, value, kc, vc, slots)
+    torch.cuda.synchronize()
+    kc_ref, vc_ref = inp["key_caches"][0].copy(), inp["value_caches"][0].copy()
+    pa_oracle.reshape_and_cache(inp["qkv"][:, 1], inp["qkv"][:, 2], kc_ref, vc_ref, inp["slot_mapping"], dtype)
+    assert np.array_equal(datagen.torch_to_storage(kc, dtype), kc_ref)
+    assert np.array_equal(datagen.torch_to_storage(vc, dtype), vc_ref)
+    # and back through the scalar gather path
+    kbuf.zero_()
+    vbuf.zero_()
+    pkg._capi.gather_cached_kv(key, value, kc, vc, slots)
+    torch.cuda.synchronize()
+    assert torch.equal(key, qkv[:, 1]) and torch.equal(value, qkv[:, 2])
+
+
+def test_reshape_and_cache_skips_negative_slots_and_empty_input(pkg):
+    import torch
+    case = datagen.CacheCase(name="neg", dtype="float16", num_tokens=4, num_heads=2, head_size=64, block_size=16,
+                             num_blocks=3, seed=9)
+    inp = datagen.make_cache_inputs(case)
+    qkv = _to_dev(inp["qkv"], "float16")
+    kc, vc = _to_dev(inp["key_caches"][0], "float16"), _to_dev(inp["value_caches"][0], "float16")
+    slots_np = inp["slot_mapping"].copy()
+    slots_np[2] = -1
+    slots = torch.from_numpy(slots_np).to(DEV)
+    pkg.cache_ops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kc, vc, slots)
+    torch.cuda.synchronize()
+    kc_ref, vc_ref = inp["key_caches"][0].copy(), inp["value_caches"][0].copy()
+    keep = [0, 1, 3]
+    pa_oracle.reshape_and_cache(np.ascontiguousarray(inp["qkv"][keep, 1]), np.ascontiguousarray(inp["qkv"][keep, 2]),
+                                kc_ref, vc_ref, slots_np[keep], "float16")
+    assert np.array_equal(datagen.torch_to_storage(kc, "float16"), kc_ref)
+    assert np.array_equal(datagen.torch_to_storage(vc, "float16"), vc_ref)
+    empty = qkv[:0]
+    pkg.cache_ops.reshape_and_cache(empty[:, 1], empty[:, 2], kc, vc, slots[:0])
+    torch.cuda.synchronize()
+
+
+def test_copy_blocks_many_pairs_and_layers_in_several_launches(pkg):
+    """More layers and pairs than one kernel-argument table holds, one source
+    fanning out to several destinations (copy-on-write for n > 2 samples)."""
+    import torch
+    L, NB, H, D, B = 100, 700, 2, 16, 8
+    g = torch.Generator(device=DEV)
+    g.manual_seed(1)
+    kcs = [torch.randn(NB, H, D // 8, B, 8, dtype=torch.float16, device=DEV, generator=g) for _ in range(L)]
+    vcs = [torch.randn(NB, H, D, B, dtype=torch.float16, device=DEV, generator=g) for _ in range(L)]
+    perm = datagen.permutation(NB, 5)
+    srcs, dsts = perm[:100], perm[100:400]
+    mapping = {int(s): [int(d) for d in dsts[3 * i:3 * i + 3]] for i, s in enumerate(srcs)}
+    ref_k = [t.cpu().numpy().copy() for t in kcs]
+    ref_v = [t.cpu().numpy().copy() for t in vcs]
+    flat_src = [s for s, ds in mapping.items() for _ in ds]
+    flat_dst = [d for _, ds in mapping.items() for d in ds]
+    pa_oracle.copy_blocks(ref_k, ref_v, flat_src, flat_dst)
+    pkg.cache_ops.copy_blocks(kcs, vcs, mapping)
+    torch.cuda.synchronize()
+    for l in range(L):
+        assert np.array_equal(kcs[l].cpu().numpy(), ref_k[l]), l
+        assert np.array_equal(vcs[l].cpu().numpy(), ref_v[l]), l
+
+
+def test_copy_blocks_narrow_word_paths(pkg):
+    """Block sizes that are not multiples of 16 bytes fall back to narrower
+    words (driven through the C ABI with byte tensors)."""
+    import torch
+    for block_bytes in (24, 36, 6, 7):
+        NB = 9
+        k = torch.arange(NB * block_bytes, dtype=torch.int64, device=DEV).to(torch.uint8).reshape(NB, block_bytes)
+        v = (k + 101).to(torch.uint8)
+        k0, v0 = k.clone(), v.clone()
+        pkg._capi.copy_blocks([k], [v], [0, 3], [5, 8])
+        torch.cuda.synchronize()
+        for s, d in ((0, 5), (3, 8)):
+            assert torch.equal(k[d], k0[s]) and torch.equal(v[d], v0[s])
+        untouched = [0, 1, 2, 3, 4, 6, 7]
+        assert torch.equal(k[untouched], k0[untouched]) and torch.equal(v[untouched], v0[untouched])
+
+
+def test_swap_blocks_gpu_cpu_round_trip_on_side_stream(pkg):
+    """CacheEngine._swap (vllm/worker/cache_engine.py:101-118): swap out to
+    pinned CPU memory and back in on a side stream, fenced by an event."""
+    import torch
+    NB_GPU, NB_CPU, H, D, B = 12, 6, 3, 64, 16
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    gpu = torch.randn(NB_GPU, H, D // 8, B, 8, dtype=torch.float16, device=DEV, generator=g)
+    gpu0 = gpu.clone()
+    cpu = torch.zeros(NB_CPU, H, D // 8, B, 8, dtype=torch.float16).pin_memory()
+    out_map = {1: 0, 2: 1, 3: 2, 7: 5, 11: 4}   # contains a mergeable run 1,2,3 -> 0,1,2
+    stream = torch.cuda.Stream()
+    event = torch.cuda.Event()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        pkg.cache_ops.swap_blocks(gpu, cpu, out_map)
+        event.record(stream=stream)
+    event.synchronize()
+    for s, d in out_map.items():
+        assert torch.equal(cpu[d], gpu0[s].cpu())
+    assert torch.count_nonzero(cpu[3]) == 0
+    gpu.zero_()
+    in_map = {d: s for s, d in out_map.items()}
+    with torch.cuda.stream(stream):
+        pkg.cache_ops.swap_blocks(cpu, gpu, in_map)
+        event.record(stream=stream)
+    event.wait()
+    torch.cuda.synchronize()
+    for s in out_map:
+        assert torch.equal(gpu[s], gpu0[s])
+    # device-to-device between two cache tensors
+    other = torch.zeros_like(gpu)
+    pkg.cache_ops.swap_blocks(gpu0, other, {0: 11, 5: 6})
+    torch.cuda.synchronize()
+    assert torch.equal(other[11], gpu0[0]) and torch.equal(other[6], gpu0[5])
+    with pytest.raises(RuntimeError, match="Invalid device combination"):
+        pkg.cache_ops.swap_blocks(cpu, cpu.clone(), {0: 1})
+
+
+def test_reshape_gather_round_trip_at_decode_step_size(pkg):
+    """LLaMA-7B decode step: 256 tokens x 32 heads x 128, block 16.  Scatter
+    then gather must return the rows bit for bit, and only the addressed slots
+    of the caches may change."""
+    import torch
+    T, H, D, B, NB = 256, 32, 128, 16, 4096
+    g = torch.Generator(device=DEV)
+    g.manual_seed(4)
+    qkv = torch.randn(T, 3, H, D, dtype=torch.float16, device=DEV, generator=g)
+    kc = torch.zeros(NB, H, D // 8, B, 8, dtype=torch.float16, device=DEV)
+    vc = torch.zeros(NB, H, D, B, dtype=torch.float16, device=DEV)
+    slots = torch.randperm(NB * B, device=DEV, generator=g)[:T].to(torch.int32)
+    pkg.cache_ops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kc, vc, slots)
+    out = torch.zeros_like(qkv)
+    pkg.cache_ops.gather_cached_kv(out[:, 1], out[:, 2], kc, vc, slots)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 1], qkv[:, 1]) and torch.equal(out[:, 2], qkv[:, 2])
+    assert torch.count_nonzero(out[:, 0]) == 0
+    # checksum of checksums: total mass moved equals the mass of the inputs
+    assert torch.equal(kc.double().sum(), qkv[:, 1].double().sum())
+    assert torch.equal(vc.double().sum(), qkv[:, 2].double().sum())
+    assert int(torch.count_nonzero(kc)) <= T * H * D and int(torch.count_nonzero(vc)) <= T * H * D

@@ -1,0 +1,215 @@
+"""GPU parity tests of decode attention, driven through the C ABI
+(libpaged_attn_mi355x.so via ctypes) and through the `attention_ops` module."""
+import numpy as np
+import pytest
+
+from oracle import datagen, pa_oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+DECODE_META, DECODE_DATA = helpers.load_decode_golden()
+
+
+def _run_capi(pkg, inp, case, device="cuda:0"):
+    import torch
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, device)
+    out = torch.full((case.num_seqs, case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=device)
+    pkg._capi.single_query_cached_kv_attention(
+        out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"])
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(DECODE_META))
+def test_decode_matches_reference_fixture(pkg, name):
+    """Every golden case: dtype x block size x head size grid at two input
+    scales, edge-case context lengths, and the reference test's own sizes
+    (37 tokens, 3 heads, 1024 blocks, context <= 4096)."""
+    entry = DECODE_META[name]
+    case = helpers.decode_case_from_meta(entry)
+    inp = datagen.make_decode_inputs(case)
+    assert datagen.checksum(inp) == entry["inputs_sha256"]
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case), case.dtype)
+    atol, rtol = helpers.TIGHT[case.dtype]
+    helpers.assert_close(got, DECODE_DATA[name + "/ref_f32"], atol, rtol, f"{name} vs reference fp32")
+    if case.dist == "uniform1e-3":
+        want = datagen.storage_to_float32(DECODE_DATA[name + "/ref_dtype"], case.dtype)
+        helpers.assert_close(got, want, helpers.REF_ATOL, helpers.REF_RTOL, f"{name} vs reference in {case.dtype}")
+
+
+@pytest.mark.parametrize("dtype", datagen.DTYPES)
+def test_decode_matches_oracle_ragged_batch(pkg, dtype):
+    """A larger ragged batch against the C oracle, including the scale
+    argument (the reference's Python oracle hard-codes 1/sqrt(d))."""
+    case = datagen.DecodeCase(name="ragged", dtype=dtype, num_seqs=33, num_heads=5, head_size=128,
+                              block_size=16, num_blocks=700, max_context=600, dist="normal",
+                              tables="permutation", scale=0.11, seed=21)
+    inp = datagen.make_decode_inputs(case)
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case), dtype)
+    ref = pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], dtype)
+    atol, rtol = helpers.TIGHT[dtype]
+    helpers.assert_close(got, datagen.storage_to_float32(ref, dtype), atol, 2 * rtol, f"ragged {dtype}")
+
+
+def test_decode_via_attention_ops_module_like_the_reference_test(pkg):
+    """tests/kernels/test_attention.py:159-224 with its input distribution
+    and tolerance, through the pybind11 module."""
+    import torch
+    for dtype in datagen.DTYPES:
+        for B in (8, 16, 32):
+            D = {8: 80, 16: 128, 32: 96}[B]
+            case = datagen.DecodeCase(name="mod", dtype=dtype, num_seqs=37, num_heads=3, head_size=D,
+                                      block_size=B, num_blocks=256, max_context=1024,
+                                      dist="uniform1e-3", seed=33 + B)
+            inp = datagen.make_decode_inputs(case)
+            qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
+            output = torch.empty(case.num_seqs, case.num_heads, D, dtype=qkv.dtype, device="cuda:0")
+            pkg.attention_ops.single_query_cached_kv_attention(
+                output, query, kc, vc, inp["scale"], bt, cl, B, inp["max_context_len"])
+            ref = pa_oracle.single_query_cached_kv_attention(
+                inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+                inp["context_lens"], dtype)
+            ref_t = datagen.storage_to_torch(ref, dtype).to("cuda:0")
+            assert torch.allclose(output, ref_t, atol=1e-3, rtol=1e-5), (dtype, B, D)
+
+
+def test_decode_masked_tail_ignores_garbage_in_the_cache(pkg):
+    """Slots past context_len in the last block may hold anything (the cache
+    is torch.empty in vllm/worker/cache_engine.py:70-79), including NaN."""
+    import torch
+    case = datagen.DecodeCase(name="nan", dtype="float16", num_seqs=4, num_heads=2, head_size=128,
+                              block_size=16, num_blocks=32, context_lens=[3, 17, 31, 16], dist="normal",
+                              tables="permutation", seed=8)
+    inp = datagen.make_decode_inputs(case)
+    ref = pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype)
+    kc, vc = inp["key_cache"], inp["value_cache"]
+    nan = np.float16(np.nan)
+    for s, c in enumerate(inp["context_lens"]):
+        last = inp["block_tables"][s, (c - 1) // 16]
+        first_bad = c % 16
+        if first_bad:
+            kc[last, :, :, first_bad:, :] = nan
+            vc[last, :, :, first_bad:] = nan
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case), case.dtype)
+    helpers.assert_close(got, datagen.storage_to_float32(ref, case.dtype), 2e-5, 1e-3, "NaN tail")
+
+
+def test_decode_zero_context_and_empty_batch(pkg):
+    import torch
+    case = datagen.DecodeCase(name="zero", dtype="float16", num_seqs=3, num_heads=2, head_size=64,
+                              block_size=16, num_blocks=8, context_lens=[0, 5, 0], dist="normal", seed=2)
+    inp = datagen.make_decode_inputs(case)
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case), case.dtype)
+    assert np.all(got[0] == 0) and np.all(got[2] == 0)
+    ref = pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype)
+    helpers.assert_close(got[1], datagen.storage_to_float32(ref, case.dtype)[1], 2e-5, 1e-3, "ctx 5")
+    # empty batch: nothing is launched, nothing is touched
+    q = torch.empty(0, 2, 64, dtype=torch.float16, device="cuda:0")
+    o = torch.empty(0, 2, 64, dtype=torch.float16, device="cuda:0")
+    kc = torch.zeros(8, 2, 8, 16, 8, dtype=torch.float16, device="cuda:0")
+    vc = torch.zeros(8, 2, 64, 16, dtype=torch.float16, device="cuda:0")
+    bt = torch.zeros(0, 1, dtype=torch.int32, device="cuda:0")
+    cl = torch.zeros(0, dtype=torch.int32, device="cuda:0")
+    pkg.attention_ops.single_query_cached_kv_attention(o, q, kc, vc, 0.125, bt, cl, 16, 0)
+    torch.cuda.synchronize()
+
+
+def test_decode_unaligned_query_rows(pkg):
+    """A query view whose rows are not 16-byte aligned takes the element-wise
+    q load path."""
+    import torch
+    case = datagen.DecodeCase(name="unal", dtype="float16", num_seqs=5, num_heads=3, head_size=80,
+                              block_size=8, num_blocks=64, max_context=90, dist="normal", seed=4)
+    inp = datagen.make_decode_inputs(case)
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+    S, H, D = query.shape
+    buf = torch.zeros(S * (H * D + 3) + 1, dtype=query.dtype, device="cuda:0")
+    q_odd = buf[1:].as_strided((S, H, D), (H * D + 3, D, 1))
+    q_odd.copy_(query)
+    out = torch.empty(S, H, D, dtype=query.dtype, device="cuda:0")
+    pkg._capi.single_query_cached_kv_attention(out, q_odd, kc, vc, inp["scale"], bt, cl, case.block_size,
+                                               inp["max_context_len"])
+    torch.cuda.synchronize()
+    ref = pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype)
+    helpers.assert_close(helpers.out_to_f32(out, case.dtype), datagen.storage_to_float32(ref, case.dtype),
+                         2e-5, 1e-3, "unaligned q")
+
+
+def test_decode_rejects_what_the_reference_rejects(pkg):
+    """Unsupported head size / block size / dtype raise, as TORCH_CHECK does in
+    csrc/attention/attention_kernels.cu:398,446,467."""
+    import torch
+    dev = "cuda:0"
+
+    def call(D, B, dtype):
+        x = 16 // torch.tensor([], dtype=dtype).element_size()
+        q = torch.zeros(2, 2, D, dtype=dtype, device=dev)
+        o = torch.zeros(2, 2, D, dtype=dtype, device=dev)
+        kc = torch.zeros(4, 2, max(D // x, 1), B, x, dtype=dtype, device=dev)
+        vc = torch.zeros(4, 2, D, B, dtype=dtype, device=dev)
+        bt = torch.zeros(2, 1, dtype=torch.int32, device=dev)
+        cl = torch.ones(2, dtype=torch.int32, device=dev)
+        pkg.attention_ops.single_query_cached_kv_attention(o, q, kc, vc, 1.0, bt, cl, B, 1)
+
+    with pytest.raises(RuntimeError, match="head size"):
+        call(32, 16, torch.float16)
+    with pytest.raises(RuntimeError, match="block size"):
+        call(64, 64, torch.float16)
+    with pytest.raises(RuntimeError, match="data type"):
+        call(64, 16, torch.float64)
+    call(64, 16, torch.float16)
+    torch.cuda.synchronize()
+
+
+def test_decode_north_star_size_properties(pkg):
+    """bs 256 / 32 heads / head 128 / ctx 1024 / block 16 fp16, distinct
+    physical blocks.  Too big for the oracle in full, so check size-independent
+    properties and a sampled subset of rows:
+      * V == 1 everywhere  => every output element is sum(p) = 1 / (1 + 1e-6 / sum e)
+      * a sample of (sequence, head) rows equals the oracle on those rows."""
+    import torch
+    dev = "cuda:0"
+    S, H, D, B, CTX = 256, 32, 128, 16, 1024
+    nb = S * CTX // B
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    qkv = torch.randn(S, 3, H, D, dtype=torch.float16, device=dev, generator=g) * 0.5
+    query = qkv[:, 0]
+    kc = torch.randn(nb, H, D // 8, B, 8, dtype=torch.float16, device=dev, generator=g) * 0.5
+    vc = torch.ones(nb, H, D, B, dtype=torch.float16, device=dev)
+    perm = torch.randperm(nb, device=dev, generator=g).to(torch.int32).reshape(S, CTX // B)
+    ctx_list = [CTX] * S
+    ctx_list[1], ctx_list[2], ctx_list[3] = 1, CTX - 15, 17
+    cl = torch.tensor(ctx_list, dtype=torch.int32, device=dev)
+    out = torch.empty(S, H, D, dtype=torch.float16, device=dev)
+    scale = 1.0 / D ** 0.5
+    pkg._capi.single_query_cached_kv_attention(out, query, kc, vc, scale, perm, cl, B, CTX)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.float(), torch.ones_like(out, dtype=torch.float32), atol=1e-3), \
+        "softmax weights do not sum to one"
+    # sampled rows against the oracle, with random V
+    vc.copy_(torch.randn(nb, H, D, B, dtype=torch.float16, device=dev, generator=g) * 0.5)
+    pkg._capi.single_query_cached_kv_attention(out, query, kc, vc, scale, perm, cl, B, CTX)
+    torch.cuda.synchronize()
+    rows = [0, 1, 2, 3, 100, 255]
+    heads = [0, 13, 31]
+    for s in rows:
+        blocks = perm[s].long()
+        # compact this sequence's blocks and the sampled heads into a small problem
+        kcs = kc[blocks][:, heads].contiguous().cpu().numpy()
+        vcs = vc[blocks][:, heads].contiguous().cpu().numpy()
+        qs = query[s:s + 1][:, heads].contiguous().cpu().numpy()
+        tbl = np.arange(len(blocks), dtype=np.int32)[None, :]
+        ref = pa_oracle.single_query_cached_kv_attention(
+            qs, kcs, vcs, scale, tbl, np.array([ctx_list[s]], dtype=np.int32), "float16")
+        got = out[s][heads].float().cpu().numpy()
+        helpers.assert_close(got, ref.astype(np.float32)[0], 2e-5, 1.5e-3, f"north-star row {s}")

@@ -1,0 +1,161 @@
+"""ctypes binding of libpaged_attn_mi355x.so (the C ABI in
+include/paged_attn_mi355x.h).
+
+This is the raw boundary: pointers and sizes only.  The torch-facing operator
+modules (`attention_ops`, `cache_ops`) are separate pybind11 extensions on top
+of the same library; this binding exists so that the C ABI itself can be
+driven and tested from Python exactly as a foreign-language host would drive
+it.  There is no fallback: if the library is missing, importing fails.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpaged_attn_mi355x.so")
+
+PA_OK = 0
+PA_ERR_INVALID_ARGUMENT = 1
+PA_ERR_UNSUPPORTED = 2
+PA_ERR_HIP = 3
+PA_DTYPE_F32, PA_DTYPE_F16, PA_DTYPE_BF16 = 0, 1, 2
+PA_COPY_DEVICE_TO_DEVICE, PA_COPY_DEVICE_TO_HOST, PA_COPY_HOST_TO_DEVICE = 0, 1, 2
+PA_ABI_VERSION = 1
+
+EXPORTS = (
+    "pa_abi_version",
+    "pa_last_error",
+    "pa_single_query_cached_kv_attention",
+    "pa_reshape_and_cache",
+    "pa_gather_cached_kv",
+    "pa_copy_blocks",
+    "pa_swap_blocks",
+)
+
+
+class PagedAttnError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[paged_attn_mi355x code {code}] {message}")
+        self.code = code
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C vllm-v0.1.0_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for this path.")
+    # torch carries its own HIP runtime; load torch first so that this library
+    # binds to the runtime the process already uses instead of a second copy.
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    lib.pa_abi_version.argtypes = []
+    lib.pa_abi_version.restype = i32
+    lib.pa_last_error.argtypes = []
+    lib.pa_last_error.restype = ctypes.c_char_p
+    lib.pa_single_query_cached_kv_attention.argtypes = [
+        vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp]
+    lib.pa_single_query_cached_kv_attention.restype = i32
+    for fn in (lib.pa_reshape_and_cache, lib.pa_gather_cached_kv):
+        fn.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
+        fn.restype = i32
+    lib.pa_copy_blocks.argtypes = [vp, vp, i32, vp, i32, i64, vp]
+    lib.pa_copy_blocks.restype = i32
+    lib.pa_swap_blocks.argtypes = [vp, vp, vp, i32, i64, i32, vp]
+    lib.pa_swap_blocks.restype = i32
+    if lib.pa_abi_version() != PA_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.pa_abi_version()} != {PA_ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.pa_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != PA_OK:
+        raise PagedAttnError(rc, last_error())
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    try:
+        return {torch.float32: PA_DTYPE_F32, torch.float16: PA_DTYPE_F16, torch.bfloat16: PA_DTYPE_BF16}[torch_dtype]
+    except KeyError:
+        return -1
+
+
+def _stream_handle(stream) -> ctypes.c_void_p:
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+
+# ---- thin helpers over torch tensors: every argument is reduced to a raw
+# pointer or integer before the call, nothing else is done here -------------
+
+def single_query_cached_kv_attention(out, query, key_cache, value_cache, scale, block_tables,
+                                     context_lens, block_size, max_context_len, stream=None,
+                                     dtype=None, head_size=None) -> None:
+    S, H, D = query.shape
+    rc = lib.pa_single_query_cached_kv_attention(
+        out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), float(scale),
+        block_tables.data_ptr(), context_lens.data_ptr(), S, H, D if head_size is None else head_size,
+        block_size, block_tables.shape[1], max_context_len, query.stride(0) if S > 0 else 0,
+        dtype_code(query.dtype) if dtype is None else dtype, _stream_handle(stream))
+    check(rc)
+
+
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, stream=None) -> None:
+    T, H, D = key.shape
+    rc = lib.pa_reshape_and_cache(
+        key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        slot_mapping.data_ptr(), T, H, D, value_cache.shape[3], key.stride(0) if T > 0 else 0,
+        value.stride(0) if T > 0 else 0, dtype_code(key.dtype), _stream_handle(stream))
+    check(rc)
+
+
+def gather_cached_kv(key, value, key_cache, value_cache, slot_mapping, stream=None) -> None:
+    T, H, D = key.shape
+    rc = lib.pa_gather_cached_kv(
+        key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        slot_mapping.data_ptr(), T, H, D, value_cache.shape[3], key.stride(0) if T > 0 else 0,
+        value.stride(0) if T > 0 else 0, dtype_code(key.dtype), _stream_handle(stream))
+    check(rc)
+
+
+def _pairs(src: Sequence[int], dst: Sequence[int]):
+    n = len(src)
+    arr = (ctypes.c_int64 * (2 * n))()
+    for i in range(n):
+        arr[2 * i] = int(src[i])
+        arr[2 * i + 1] = int(dst[i])
+    return arr
+
+
+def copy_blocks(key_caches, value_caches, src: Sequence[int], dst: Sequence[int], stream=None) -> None:
+    L = len(key_caches)
+    kp = (ctypes.c_void_p * max(L, 1))(*[t.data_ptr() for t in key_caches])
+    vp = (ctypes.c_void_p * max(L, 1))(*[t.data_ptr() for t in value_caches])
+    block_bytes = key_caches[0][0].numel() * key_caches[0].element_size() if L else 0
+    rc = lib.pa_copy_blocks(kp, vp, L, _pairs(src, dst), len(src), block_bytes, _stream_handle(stream))
+    check(rc)
+
+
+def swap_blocks(src_cache, dst_cache, src: Sequence[int], dst: Sequence[int], stream=None) -> None:
+    if src_cache.is_cuda and dst_cache.is_cuda:
+        kind = PA_COPY_DEVICE_TO_DEVICE
+    elif src_cache.is_cuda:
+        kind = PA_COPY_DEVICE_TO_HOST
+    else:
+        kind = PA_COPY_HOST_TO_DEVICE
+    block_bytes = src_cache[0].numel() * src_cache.element_size()
+    rc = lib.pa_swap_blocks(src_cache.data_ptr(), dst_cache.data_ptr(), _pairs(src, dst), len(src),
+                            block_bytes, kind, _stream_handle(stream))
+    check(rc)

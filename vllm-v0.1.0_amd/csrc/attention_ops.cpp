@@ -1,0 +1,55 @@
+// Python module `attention_ops`: same name, function and argument order as
+// vLLM v0.1.0's csrc/attention.cpp:3-19, so
+// vllm/model_executor/layers/attention.py:81-91 calls it unchanged.
+#include "torch_shim.h"
+
+namespace {
+
+void single_query_cached_kv_attention(
+    torch::Tensor& out,           // [num_seqs, num_heads, head_size]
+    torch::Tensor& query,         // [num_seqs, num_heads, head_size]
+    torch::Tensor& key_cache,     // [num_blocks, num_heads, head_size/x, block_size, x]
+    torch::Tensor& value_cache,   // [num_blocks, num_heads, head_size, block_size]
+    float scale,
+    torch::Tensor& block_tables,  // [num_seqs, max_num_blocks_per_seq]
+    torch::Tensor& context_lens,  // [num_seqs]
+    int block_size, int max_context_len) {
+  using namespace pa_shim;
+  const char* what = "single_query_cached_kv_attention";
+  TORCH_CHECK(query.is_cuda() && out.is_cuda() && key_cache.is_cuda() && value_cache.is_cuda() &&
+                  block_tables.is_cuda() && context_lens.is_cuda(),
+              what, ": all tensors must be on the GPU");
+  const int dtype = dtype_code(query, what);
+  TORCH_CHECK(out.scalar_type() == query.scalar_type() && key_cache.scalar_type() == query.scalar_type() &&
+                  value_cache.scalar_type() == query.scalar_type(),
+              what, ": out, query, key_cache and value_cache must share one data type");
+  check_token_rows(query, "query");
+  TORCH_CHECK(out.dim() == 3 && out.is_contiguous(), what, ": out must be a contiguous [num_seqs, num_heads, head_size]");
+  TORCH_CHECK(out.sizes() == query.sizes(), what, ": out and query shapes differ");
+  TORCH_CHECK(key_cache.dim() == 5 && value_cache.dim() == 4 && key_cache.is_contiguous() && value_cache.is_contiguous(),
+              what, ": key_cache must be a contiguous 5-d tensor and value_cache a contiguous 4-d tensor");
+  TORCH_CHECK(block_tables.scalar_type() == at::ScalarType::Int && context_lens.scalar_type() == at::ScalarType::Int,
+              what, ": block_tables and context_lens must be int32");
+  TORCH_CHECK(block_tables.dim() == 2 && block_tables.is_contiguous() && context_lens.is_contiguous(), what,
+              ": block_tables must be a contiguous 2-d tensor and context_lens contiguous");
+  const int num_seqs = query.size(0), num_heads = query.size(1), head_size = query.size(2);
+  TORCH_CHECK(block_tables.size(0) == num_seqs && context_lens.numel() == num_seqs, what,
+              ": block_tables / context_lens do not match the number of sequences");
+  TORCH_CHECK(value_cache.size(1) == num_heads && value_cache.size(2) == head_size && value_cache.size(3) == block_size,
+              what, ": value_cache shape does not match [num_blocks, ", num_heads, ", ", head_size, ", ", block_size, "]");
+  TORCH_CHECK(key_cache.numel() == value_cache.numel() && key_cache.size(3) == block_size, what,
+              ": key_cache shape does not match value_cache");
+  check_status(pa_single_query_cached_kv_attention(
+                   out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
+                   block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), num_seqs, num_heads, head_size,
+                   block_size, static_cast<int>(block_tables.size(1)), max_context_len,
+                   num_seqs > 0 ? query.stride(0) : 0, dtype, current_stream(query)),
+               what);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("single_query_cached_kv_attention", &single_query_cached_kv_attention,
+        "Attention of one new query token per sequence over the paged key/value cache (MI355X HIP kernel)");
+}

@@ -1,0 +1,289 @@
+// KV-cache maintenance kernels for gfx950 (MI355X): reshape_and_cache,
+// gather_cached_kv, copy_blocks, swap_blocks.  They replace
+// csrc/cache_kernels.cu of vLLM v0.1.0.  All of them are byte movers, so they
+// are written over raw 16-byte vectors and element-sized words; the element
+// type only enters through its size.  Offsets are 64-bit throughout.
+#include <vector>
+
+#include "pa_common.h"
+
+namespace pa {
+
+template <int BYTES> struct Word;
+template <> struct Word<1> { typedef uint8_t type; };
+template <> struct Word<2> { typedef uint16_t type; };
+template <> struct Word<4> { typedef uint32_t type; };
+template <> struct Word<8> { typedef u32x2 type; };
+template <> struct Word<16> { typedef u32x4 type; };
+
+// ---- reshape_and_cache / gather_cached_kv ------------------------------------
+//
+// One workgroup per token.  The token's H*D elements are walked in 16-byte
+// vectors of X = 16/ES elements: a K vector is exactly one innermost [x] run
+// of the key cache (one 16-byte access on both sides); the X elements of a V
+// vector land B elements apart in the value cache (element-sized accesses on
+// the cache side, one 16-byte access on the token side).
+//
+// GATHER = false: token rows -> caches (reference reshape_and_cache_kernel,
+//                 csrc/cache_kernels.cu:143-182)
+// GATHER = true : caches -> token rows (gather_cached_kv_kernel, :230-270)
+// VEC = false is the element-wise fallback for token rows that are not
+// 16-byte aligned.
+template <int ES, bool GATHER, bool VEC>
+__global__ void __launch_bounds__(256)
+pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __restrict__ key_cache,
+                      char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_heads,
+                      const int head_size, const int block_size, const int64_t key_stride_bytes,
+                      const int64_t value_stride_bytes) {
+  typedef typename Word<ES>::type elem_t;
+  constexpr int X = 16 / ES;
+  const int token = blockIdx.x;
+  const int slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int off = slot % block_size;
+  const int n = num_heads * head_size;
+  char* krow = key + (int64_t)token * key_stride_bytes;
+  char* vrow = value + (int64_t)token * value_stride_bytes;
+  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
+
+  if (VEC) {
+    const int nvec = n / X;
+    const int ndx = head_size / X;
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+      const int h = i / ndx;
+      const int dx = i - h * ndx;
+      // key cache [blk][h][dx][off][x]
+      const int64_t kc_el = cache_block + (((int64_t)h * ndx + dx) * block_size + off) * X;
+      // value cache [blk][h][d][off], d = dx * X + e
+      const int64_t vc_el = cache_block + ((int64_t)h * head_size + (int64_t)dx * X) * block_size + off;
+      u32x4* ktok = reinterpret_cast<u32x4*>(krow + (int64_t)i * 16);
+      u32x4* vtok = reinterpret_cast<u32x4*>(vrow + (int64_t)i * 16);
+      u32x4* kc = reinterpret_cast<u32x4*>(key_cache + kc_el * ES);
+      elem_t* vc = reinterpret_cast<elem_t*>(value_cache + vc_el * ES);
+      if (!GATHER) {
+        const u32x4 kv = *ktok;
+        const u32x4 vv = *vtok;
+        *kc = kv;
+        elem_t tmp[X];
+        __builtin_memcpy(tmp, &vv, 16);
+#pragma unroll
+        for (int e = 0; e < X; e++) vc[(int64_t)e * block_size] = tmp[e];
+      } else {
+        const u32x4 kv = *kc;
+        elem_t tmp[X];
+#pragma unroll
+        for (int e = 0; e < X; e++) tmp[e] = vc[(int64_t)e * block_size];
+        u32x4 vv;
+        __builtin_memcpy(&vv, tmp, 16);
+        *ktok = kv;
+        *vtok = vv;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int h = i / head_size;
+      const int d = i - h * head_size;
+      const int64_t kc_el = cache_block + ((((int64_t)h * (head_size / X) + d / X) * block_size + off) * X) + d % X;
+      const int64_t vc_el = cache_block + ((int64_t)h * head_size + d) * block_size + off;
+      elem_t* ktok = reinterpret_cast<elem_t*>(krow) + i;
+      elem_t* vtok = reinterpret_cast<elem_t*>(vrow) + i;
+      elem_t* kc = reinterpret_cast<elem_t*>(key_cache) + kc_el;
+      elem_t* vc = reinterpret_cast<elem_t*>(value_cache) + vc_el;
+      if (!GATHER) {
+        *kc = *ktok;
+        *vc = *vtok;
+      } else {
+        *ktok = *kc;
+        *vtok = *vc;
+      }
+    }
+  }
+}
+
+template <bool GATHER>
+static int token_cache_op(const char* what, void* key, void* value, void* key_cache, void* value_cache,
+                          const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+                          int block_size, int64_t key_stride, int64_t value_stride, int dtype, void* stream) {
+  clear_error();
+  if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
+    return fail(PA_ERR_UNSUPPORTED, "%s: unsupported data type code: %d", what, dtype);
+  PA_REQUIRE(num_tokens >= 0 && num_heads >= 0 && head_size >= 0 && block_size > 0,
+             "%s: negative size or non-positive block size", what);
+  if (num_tokens == 0 || num_heads == 0 || head_size == 0) return PA_OK;
+  PA_REQUIRE(key && value && key_cache && value_cache && slot_mapping, "%s: null pointer argument", what);
+  const int es = elem_size(dtype);
+  const int x = 16 / es;
+  PA_REQUIRE(head_size % x == 0, "%s: head_size %d is not a multiple of x = %d", what, head_size, x);
+  PA_REQUIRE(aligned16(key_cache), "%s: key_cache must be 16-byte aligned", what);
+  PA_REQUIRE((int64_t)num_heads * head_size < (1ll << 31), "%s: num_heads * head_size too large", what);
+  const bool vec = aligned16(key) && aligned16(value) && (key_stride * es) % 16 == 0 && (value_stride * es) % 16 == 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nvec = num_heads * head_size / x;
+  int threads = vec ? nvec : num_heads * head_size;
+  threads = threads < 64 ? 64 : (threads > 256 ? 256 : (threads + 63) / 64 * 64);
+  char* k = static_cast<char*>(key);
+  char* v = static_cast<char*>(value);
+  char* kc = static_cast<char*>(key_cache);
+  char* vc = static_cast<char*>(value_cache);
+#define PA_LAUNCH_TOKEN(ES, VEC)                                                                              \
+  hipLaunchKernelGGL((pa_token_cache_kernel<ES, GATHER, VEC>), dim3(num_tokens), dim3(threads), 0, st, k, v, \
+                     kc, vc, slot_mapping, num_heads, head_size, block_size, key_stride * ES, value_stride * ES)
+  if (es == 2) {
+    if (vec) PA_LAUNCH_TOKEN(2, true); else PA_LAUNCH_TOKEN(2, false);
+  } else {
+    if (vec) PA_LAUNCH_TOKEN(4, true); else PA_LAUNCH_TOKEN(4, false);
+  }
+#undef PA_LAUNCH_TOKEN
+  PA_CHECK_LAUNCH(what);
+  return PA_OK;
+}
+
+// ---- copy_blocks ---------------------------------------------------------------
+//
+// The layer pointer table and the (src, dst) pairs ride in the kernel
+// arguments (a few KB), so the host neither allocates device memory nor waits
+// for a copy — the reference does three blocking host-to-device copies per
+// call (csrc/cache_kernels.cu:116-121).  Larger tables are cut into several
+// launches.  grid = (pairs, layers, 2 * splits): z < splits copies a slice of
+// the key block, z >= splits the same slice of the value block.
+constexpr int kCopyMaxLayers = 96;
+constexpr int kCopyMaxPairs = 256;
+
+struct CopyTable {
+  char* key_ptr[kCopyMaxLayers];
+  char* value_ptr[kCopyMaxLayers];
+  int32_t src[kCopyMaxPairs];
+  int32_t dst[kCopyMaxPairs];
+};
+
+template <int W>
+__global__ void __launch_bounds__(256)
+pa_copy_blocks_kernel(const CopyTable tab, const int64_t block_bytes, const int splits) {
+  typedef typename Word<W>::type word_t;
+  const int pair = blockIdx.x, layer = blockIdx.y;
+  const int z = blockIdx.z;
+  const bool is_value = z >= splits;
+  const int part = is_value ? z - splits : z;
+  char* base = is_value ? tab.value_ptr[layer] : tab.key_ptr[layer];
+  const word_t* __restrict__ s = reinterpret_cast<const word_t*>(base + (int64_t)tab.src[pair] * block_bytes);
+  word_t* __restrict__ d = reinterpret_cast<word_t*>(base + (int64_t)tab.dst[pair] * block_bytes);
+  const int64_t nwords = block_bytes / W;
+  const int64_t per = (nwords + splits - 1) / splits;
+  const int64_t lo = per * part;
+  const int64_t hi = lo + per < nwords ? lo + per : nwords;
+  int64_t i = lo + threadIdx.x;
+  // four independent 16-byte loads in flight per lane before the first store
+  for (; i + 3 * 256 < hi; i += 4 * 256) {
+    const word_t a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+    d[i] = a;
+    d[i + 256] = b;
+    d[i + 512] = c;
+    d[i + 768] = e;
+  }
+  for (; i < hi; i += 256) d[i] = s[i];
+}
+
+}  // namespace pa
+
+extern "C" int pa_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
+                                    const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+                                    int block_size, int64_t key_stride, int64_t value_stride, int dtype,
+                                    void* stream) {
+  return pa::token_cache_op<false>("pa_reshape_and_cache", const_cast<void*>(key), const_cast<void*>(value),
+                                   key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+                                   block_size, key_stride, value_stride, dtype, stream);
+}
+
+extern "C" int pa_gather_cached_kv(void* key, void* value, const void* key_cache, const void* value_cache,
+                                   const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+                                   int block_size, int64_t key_stride, int64_t value_stride, int dtype,
+                                   void* stream) {
+  return pa::token_cache_op<true>("pa_gather_cached_kv", key, value, const_cast<void*>(key_cache),
+                                  const_cast<void*>(value_cache), slot_mapping, num_tokens, num_heads, head_size,
+                                  block_size, key_stride, value_stride, dtype, stream);
+}
+
+extern "C" int pa_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs, int num_layers,
+                              const int64_t* block_pairs, int num_pairs, int64_t block_bytes, void* stream) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(num_layers >= 0 && num_pairs >= 0 && block_bytes >= 0, "pa_copy_blocks: negative size");
+  if (num_layers == 0 || num_pairs == 0 || block_bytes == 0) return PA_OK;
+  PA_REQUIRE(key_cache_ptrs && value_cache_ptrs && block_pairs, "pa_copy_blocks: null pointer argument");
+  // widest word that divides the block size and every base pointer
+  uintptr_t align_bits = static_cast<uintptr_t>(block_bytes);
+  for (int l = 0; l < num_layers; l++) {
+    PA_REQUIRE(key_cache_ptrs[l] && value_cache_ptrs[l], "pa_copy_blocks: null cache pointer for layer %d", l);
+    align_bits |= reinterpret_cast<uintptr_t>(key_cache_ptrs[l]) | reinterpret_cast<uintptr_t>(value_cache_ptrs[l]);
+  }
+  for (int p = 0; p < 2 * num_pairs; p++)
+    PA_REQUIRE(block_pairs[p] >= 0 && block_pairs[p] < (1ll << 31), "pa_copy_blocks: block number out of range");
+  int w = 16;
+  while (w > 1 && (align_bits & (uintptr_t)(w - 1))) w >>= 1;
+  const int64_t nwords = block_bytes / w;
+  // ~16 KiB of 16-byte words per workgroup
+  int splits = (int)((nwords + 1023) / 1024);
+  if (splits < 1) splits = 1;
+  if (splits > 1024) splits = 1024;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CopyTable tab;
+  for (int l0 = 0; l0 < num_layers; l0 += kCopyMaxLayers) {
+    const int nl = num_layers - l0 < kCopyMaxLayers ? num_layers - l0 : kCopyMaxLayers;
+    for (int l = 0; l < nl; l++) {
+      tab.key_ptr[l] = static_cast<char*>(key_cache_ptrs[l0 + l]);
+      tab.value_ptr[l] = static_cast<char*>(value_cache_ptrs[l0 + l]);
+    }
+    for (int p0 = 0; p0 < num_pairs; p0 += kCopyMaxPairs) {
+      const int np = num_pairs - p0 < kCopyMaxPairs ? num_pairs - p0 : kCopyMaxPairs;
+      for (int p = 0; p < np; p++) {
+        tab.src[p] = (int32_t)block_pairs[2 * (p0 + p)];
+        tab.dst[p] = (int32_t)block_pairs[2 * (p0 + p) + 1];
+      }
+      const dim3 grid(np, nl, 2 * splits);
+      switch (w) {
+        case 16: hipLaunchKernelGGL((pa_copy_blocks_kernel<16>), grid, dim3(256), 0, st, tab, block_bytes, splits); break;
+        case 8: hipLaunchKernelGGL((pa_copy_blocks_kernel<8>), grid, dim3(256), 0, st, tab, block_bytes, splits); break;
+        case 4: hipLaunchKernelGGL((pa_copy_blocks_kernel<4>), grid, dim3(256), 0, st, tab, block_bytes, splits); break;
+        case 2: hipLaunchKernelGGL((pa_copy_blocks_kernel<2>), grid, dim3(256), 0, st, tab, block_bytes, splits); break;
+        default: hipLaunchKernelGGL((pa_copy_blocks_kernel<1>), grid, dim3(256), 0, st, tab, block_bytes, splits); break;
+      }
+      PA_CHECK_LAUNCH("pa_copy_blocks launch");
+    }
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_swap_blocks(const void* src, void* dst, const int64_t* block_pairs, int num_pairs,
+                              int64_t block_bytes, int kind, void* stream) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(num_pairs >= 0 && block_bytes >= 0, "pa_swap_blocks: negative size");
+  if (num_pairs == 0 || block_bytes == 0) return PA_OK;
+  PA_REQUIRE(src && dst && block_pairs, "pa_swap_blocks: null pointer argument");
+  hipMemcpyKind k;
+  switch (kind) {
+    case PA_COPY_DEVICE_TO_DEVICE: k = hipMemcpyDeviceToDevice; break;
+    case PA_COPY_DEVICE_TO_HOST: k = hipMemcpyDeviceToHost; break;
+    case PA_COPY_HOST_TO_DEVICE: k = hipMemcpyHostToDevice; break;
+    default: return fail(PA_ERR_INVALID_ARGUMENT, "pa_swap_blocks: invalid device combination (kind %d)", kind);
+  }
+  for (int p = 0; p < 2 * num_pairs; p++)
+    PA_REQUIRE(block_pairs[p] >= 0, "pa_swap_blocks: negative block number");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const char* s = static_cast<const char*>(src);
+  char* d = static_cast<char*>(dst);
+  // merge runs of consecutive source AND destination blocks into one copy
+  int p = 0;
+  while (p < num_pairs) {
+    int run = 1;
+    while (p + run < num_pairs && block_pairs[2 * (p + run)] == block_pairs[2 * p] + run &&
+           block_pairs[2 * (p + run) + 1] == block_pairs[2 * p + 1] + run)
+      run++;
+    hipError_t e = hipMemcpyAsync(d + block_pairs[2 * p + 1] * block_bytes, s + block_pairs[2 * p] * block_bytes,
+                                  (size_t)(run * block_bytes), k, st);
+    if (e != hipSuccess) return fail(PA_ERR_HIP, "pa_swap_blocks: hipMemcpyAsync: %s", hipGetErrorString(e));
+    p += run;
+  }
+  return PA_OK;
+}
