@@ -27,6 +27,7 @@
 #ifndef PAGED_ATTN_MI355X_H_
 #define PAGED_ATTN_MI355X_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -86,6 +87,30 @@ int pa_single_query_cached_kv_attention(
     int num_seqs, int num_heads, int head_size, int block_size,
     int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
     int dtype, void* stream);
+
+/*
+ * Same operation with a caller-provided scratch buffer.  With a workspace of
+ * at least pa_decode_workspace_bytes(...) bytes (device memory, 4-byte
+ * aligned, contents irrelevant, may be reused by the next call on the same
+ * stream) the library may split every sequence's context into partitions that
+ * run as separate workgroups and are combined by a second kernel; it does so
+ * when num_seqs * num_heads alone cannot fill the GPU (small batches).  With
+ * workspace == NULL, or one that is too small, it behaves exactly like
+ * pa_single_query_cached_kv_attention.  Results agree with the unsplit kernel
+ * up to fp32 summation order.  No counterpart in the reference, whose kernel
+ * always runs one thread block per (sequence, head) (:367).
+ *
+ * pa_decode_workspace_bytes returns 0 when the library would not split.
+ */
+size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size,
+                                 int block_size, int max_context_len);
+
+int pa_single_query_cached_kv_attention_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    float scale, const int32_t* block_tables, const int32_t* context_lens,
+    int num_seqs, int num_heads, int head_size, int block_size,
+    int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
+    int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Scatter new key/value vectors into the paged caches.

@@ -11,18 +11,30 @@ pytestmark = pytest.mark.gpu
 DECODE_META, DECODE_DATA = helpers.load_decode_golden()
 
 
-def _run_capi(pkg, inp, case, device="cuda:0"):
+def _run_capi(pkg, inp, case, device="cuda:0", split=False):
+    """split=False: pa_single_query_cached_kv_attention (one workgroup per
+    row).  split=True: the _ws entry point with the workspace it asks for, so
+    small batches take the partitioned kernel + merge kernel."""
     import torch
     qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, device)
     out = torch.full((case.num_seqs, case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=device)
-    pkg._capi.single_query_cached_kv_attention(
-        out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"])
+    if split:
+        nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size,
+                                                  case.block_size, inp["max_context_len"])
+        ws = torch.full((max(nbytes, 4) // 4,), float("nan"), dtype=torch.float32, device=device)
+        pkg._capi.single_query_cached_kv_attention_ws(
+            out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"],
+            ws if nbytes else None)
+    else:
+        pkg._capi.single_query_cached_kv_attention(
+            out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"])
     torch.cuda.synchronize()
     return out
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["rows", "partitioned"])
 @pytest.mark.parametrize("name", sorted(DECODE_META))
-def test_decode_matches_reference_fixture(pkg, name):
+def test_decode_matches_reference_fixture(pkg, name, split):
     """Every golden case: dtype x block size x head size grid at two input
     scales, edge-case context lengths, and the reference test's own sizes
     (37 tokens, 3 heads, 1024 blocks, context <= 4096)."""
@@ -30,7 +42,7 @@ def test_decode_matches_reference_fixture(pkg, name):
     case = helpers.decode_case_from_meta(entry)
     inp = datagen.make_decode_inputs(case)
     assert datagen.checksum(inp) == entry["inputs_sha256"]
-    got = helpers.out_to_f32(_run_capi(pkg, inp, case), case.dtype)
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=split), case.dtype)
     atol, rtol = helpers.TIGHT[case.dtype]
     helpers.assert_close(got, DECODE_DATA[name + "/ref_f32"], atol, rtol, f"{name} vs reference fp32")
     if case.dist == "uniform1e-3":
@@ -38,15 +50,47 @@ def test_decode_matches_reference_fixture(pkg, name):
         helpers.assert_close(got, want, helpers.REF_ATOL, helpers.REF_RTOL, f"{name} vs reference in {case.dtype}")
 
 
+def test_partition_plan_splits_small_batches_only(pkg):
+    c = pkg._capi
+    # 256 x 32 rows fill the chip on their own: no workspace wanted
+    assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == 0
+    # one sequence: 32 rows -> split into partitions of at least 64 tokens / 4 blocks
+    n = c.decode_workspace_bytes(1, 32, 128, 16, 1024)
+    assert n > 0 and n % ((128 + 2) * 4 * 32) == 0
+    parts = n // ((128 + 2) * 4 * 32)
+    assert 2 <= parts <= 16
+    # a context that is a single partition long is never split
+    assert c.decode_workspace_bytes(1, 1, 64, 16, 64) == 0
+    assert c.decode_workspace_bytes(0, 32, 128, 16, 1024) == 0
+
+
+def test_partitioned_decode_context_longer_than_announced(pkg):
+    """The partition plan is made from max_context_len; a longer context_len
+    (caller error in the reference too, where it overruns shared memory) must
+    still be attended in full: the last partition runs to the end."""
+    import torch
+    case = datagen.DecodeCase(name="over", dtype="float16", num_seqs=2, num_heads=2, head_size=64,
+                              block_size=16, num_blocks=64, context_lens=[300, 40], dist="normal",
+                              tables="permutation", seed=12)
+    inp = datagen.make_decode_inputs(case)
+    ref = pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype)
+    inp["max_context_len"] = 200  # understated
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=True), case.dtype)
+    helpers.assert_close(got, datagen.storage_to_float32(ref, case.dtype), 2e-5, 1e-3, "understated max_context_len")
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["rows", "partitioned"])
 @pytest.mark.parametrize("dtype", datagen.DTYPES)
-def test_decode_matches_oracle_ragged_batch(pkg, dtype):
+def test_decode_matches_oracle_ragged_batch(pkg, dtype, split):
     """A larger ragged batch against the C oracle, including the scale
     argument (the reference's Python oracle hard-codes 1/sqrt(d))."""
     case = datagen.DecodeCase(name="ragged", dtype=dtype, num_seqs=33, num_heads=5, head_size=128,
                               block_size=16, num_blocks=700, max_context=600, dist="normal",
                               tables="permutation", scale=0.11, seed=21)
     inp = datagen.make_decode_inputs(case)
-    got = helpers.out_to_f32(_run_capi(pkg, inp, case), dtype)
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=split), dtype)
     ref = pa_oracle.single_query_cached_kv_attention(
         inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
         inp["context_lens"], dtype)

@@ -28,6 +28,8 @@ EXPORTS = (
     "pa_abi_version",
     "pa_last_error",
     "pa_single_query_cached_kv_attention",
+    "pa_single_query_cached_kv_attention_ws",
+    "pa_decode_workspace_bytes",
     "pa_reshape_and_cache",
     "pa_gather_cached_kv",
     "pa_copy_blocks",
@@ -58,6 +60,11 @@ def _load() -> ctypes.CDLL:
     lib.pa_single_query_cached_kv_attention.argtypes = [
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp]
     lib.pa_single_query_cached_kv_attention.restype = i32
+    lib.pa_single_query_cached_kv_attention_ws.argtypes = [
+        vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, vp]
+    lib.pa_single_query_cached_kv_attention_ws.restype = i32
+    lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
     for fn in (lib.pa_reshape_and_cache, lib.pa_gather_cached_kv):
         fn.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
         fn.restype = i32
@@ -109,6 +116,25 @@ def single_query_cached_kv_attention(out, query, key_cache, value_cache, scale, 
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D if head_size is None else head_size,
         block_size, block_tables.shape[1], max_context_len, query.stride(0) if S > 0 else 0,
         dtype_code(query.dtype) if dtype is None else dtype, _stream_handle(stream))
+    check(rc)
+
+
+def decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len) -> int:
+    return int(lib.pa_decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len))
+
+
+def single_query_cached_kv_attention_ws(out, query, key_cache, value_cache, scale, block_tables,
+                                        context_lens, block_size, max_context_len, workspace,
+                                        stream=None) -> None:
+    """`workspace` is a device tensor (any dtype) or None."""
+    S, H, D = query.shape
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    rc = lib.pa_single_query_cached_kv_attention_ws(
+        out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), float(scale),
+        block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
+        max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
+        _stream_handle(stream))
     check(rc)
 
 

@@ -39,11 +39,21 @@ void single_query_cached_kv_attention(
               what, ": value_cache shape does not match [num_blocks, ", num_heads, ", ", head_size, ", ", block_size, "]");
   TORCH_CHECK(key_cache.numel() == value_cache.numel() && key_cache.size(3) == block_size, what,
               ": key_cache shape does not match value_cache");
-  check_status(pa_single_query_cached_kv_attention(
+  // Small batches are split over more workgroups; the scratch for that comes
+  // from torch's caching allocator (no hipMalloc in steady state) and is
+  // handed back as soon as the launches are queued: the allocator reuses it in
+  // stream order, and every launch below is on the current stream.
+  const size_t ws_bytes = pa_decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len);
+  torch::Tensor workspace;
+  if (ws_bytes > 0) {
+    workspace = torch::empty({static_cast<int64_t>(ws_bytes)}, query.options().dtype(torch::kUInt8));
+  }
+  check_status(pa_single_query_cached_kv_attention_ws(
                    out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
                    block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), num_seqs, num_heads, head_size,
                    block_size, static_cast<int>(block_tables.size(1)), max_context_len,
-                   num_seqs > 0 ? query.stride(0) : 0, dtype, current_stream(query)),
+                   num_seqs > 0 ? query.stride(0) : 0, dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr,
+                   ws_bytes, current_stream(query)),
                what);
 }
 

@@ -27,6 +27,7 @@
 // :240-251); the softmax denominator is (sum + 1e-6) as in the reference
 // (:213).  Offsets are 64-bit.
 #include <float.h>
+#include <stdlib.h>
 
 #include "pa_common.h"
 
@@ -129,13 +130,47 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //  token vector tv of rows d = r, r + RPL, ... (RPL = 64 / VT rows per load),
 //  again 1 KiB contiguous per instruction.  The probabilities of the lane's X
 //  tokens come from a per-wave LDS strip written by the K-side lanes.
-template <typename E, int D, int B, int NW>
-__global__ void __launch_bounds__(NW * 64)
-pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storage* __restrict__ q,
-                 const typename E::storage* __restrict__ k_cache, const typename E::storage* __restrict__ v_cache,
-                 const float scale_log2e, const int* __restrict__ block_tables,
-                 const int* __restrict__ context_lens, const int num_seqs, const int num_heads,
-                 const int max_blocks_per_seq, const int64_t q_stride, const int q_vec_ok) {
+//
+// PART = false: one workgroup per (sequence, head) walks the whole context and
+//   writes the normalised output row.
+// PART = true : one workgroup per (sequence, head, partition) walks
+//   blocks_per_part KV blocks and writes its un-normalised (max, sum,
+//   accumulator) triple to a workspace; pa_decode_merge_kernel combines the
+//   partitions.  This spreads few or very uneven sequences over the whole chip.
+
+struct DecodeArgs {
+  void* out;
+  const void* q;
+  const void* k_cache;
+  const void* v_cache;
+  const int* block_tables;
+  const int* context_lens;
+  float* ws_acc;  // [num_seqs * num_heads * num_parts][D]   (PART only)
+  float* ws_ml;   // [num_seqs * num_heads * num_parts][2]   (PART only)
+  int64_t q_stride;
+  float scale_log2e;
+  int num_seqs;
+  int num_heads;
+  int max_blocks_per_seq;
+  int q_vec_ok;
+  int num_parts;
+  int blocks_per_part;
+};
+
+#ifndef PA_DECODE_NT
+#define PA_DECODE_NT 0
+#endif
+
+__device__ __forceinline__ u32x4 load16(const char* p) {
+#if PA_DECODE_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+  return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+
+template <typename E, int D, int B, int NW, bool PART>
+__global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) {
   typedef typename E::storage T;
   constexpr int X = E::kX;
   constexpr int NDX = D / X;
@@ -159,13 +194,23 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
   // head-major work order: the workgroups of one XCD walk consecutive
   // sequences of the same head, so sequences that share physical blocks
   // (parallel sampling, beam search) meet in one L2.
-  const unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int head = work / (unsigned)num_seqs;
-  const int seq = work - head * (unsigned)num_seqs;
+  unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
+  int part = 0;
+  if (PART) {
+    part = work % (unsigned)a.num_parts;
+    work /= (unsigned)a.num_parts;
+  }
+  const int head = work / (unsigned)a.num_seqs;
+  const int seq = work - head * (unsigned)a.num_seqs;
 
-  const int ctx = context_lens[seq];
-  const int nblk = (ctx + B - 1) / B;
-  const int* __restrict__ table = block_tables + (int64_t)seq * max_blocks_per_seq;
+  const int ctx = a.context_lens[seq];
+  const int nblk_seq = (ctx + B - 1) / B;
+  const int blk_begin = PART ? part * a.blocks_per_part : 0;
+  // the last partition runs to the end of the context even if the context is
+  // longer than the max_context_len the partition plan was made for
+  const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + a.blocks_per_part) : nblk_seq;
+  if (PART && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
+  const int* __restrict__ table = a.block_tables + (int64_t)seq * a.max_blocks_per_seq;
 
   const int t = lane % B, j = lane / B;
   const int tv = lane % VT, r = lane / VT;
@@ -173,13 +218,13 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
   // q slices of this lane (kept in the storage type; products are fp32)
   u32x4 qv[NK];
   {
-    const T* qp = q + (int64_t)seq * q_stride + (int64_t)head * D;
+    const T* qp = static_cast<const T*>(a.q) + (int64_t)seq * a.q_stride + (int64_t)head * D;
 #pragma unroll
     for (int i = 0; i < NK; i++) {
       const int dx = j + KJ * i;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (dx < NDX) {
-        if (q_vec_ok) {
+        if (a.q_vec_ok) {
           v = *reinterpret_cast<const u32x4*>(qp + dx * X);
         } else {
           T tmp[X];
@@ -192,24 +237,24 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
     }
   }
 
-  const char* kbase = reinterpret_cast<const char*>(k_cache) + (int64_t)head * TILE_BYTES;
-  const char* vbase = reinterpret_cast<const char*>(v_cache) + (int64_t)head * TILE_BYTES;
-  const int64_t block_stride = (int64_t)num_heads * TILE_BYTES;
-  const int k_lane_off = (j * B + t) * 16;   // == lane * 16
-  const int v_lane_off = (r * VT + tv) * 16; // == lane * 16
+  const char* kbase = static_cast<const char*>(a.k_cache) + (int64_t)head * TILE_BYTES + lane * 16;
+  const char* vbase = static_cast<const char*>(a.v_cache) + (int64_t)head * TILE_BYTES + lane * 16;
+  const int64_t block_stride = (int64_t)a.num_heads * TILE_BYTES;
 
   struct Tile {
     u32x4 k[NK];
     u32x4 v[NV];
   };
 
+  // lane l reads bytes [l*16, l*16+16) of every 1 KiB slice of the tile: for K
+  // that is (dx = j + KJ*i, token t), for V (row r + RPL*i, token vector tv)
   auto load_tile = [&](Tile& tl, int phys) {
-    const char* kp = kbase + (int64_t)phys * block_stride + k_lane_off;
-    const char* vp = vbase + (int64_t)phys * block_stride + v_lane_off;
+    const char* kp = kbase + (int64_t)phys * block_stride;
+    const char* vp = vbase + (int64_t)phys * block_stride;
 #pragma unroll
     for (int i = 0; i < NK; i++) {
       if ((NDX % KJ == 0) || (j + KJ * i < NDX)) {
-        tl.k[i] = *reinterpret_cast<const u32x4*>(kp + i * 1024);
+        tl.k[i] = load16(kp + i * 1024);
       } else {
         tl.k[i] = u32x4{0u, 0u, 0u, 0u};
       }
@@ -217,7 +262,7 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       if ((D % RPL == 0) || (r + RPL * i < D)) {
-        tl.v[i] = *reinterpret_cast<const u32x4*>(vp + i * 1024);
+        tl.v[i] = load16(vp + i * 1024);
       } else {
         tl.v[i] = u32x4{0u, 0u, 0u, 0u};
       }
@@ -236,7 +281,7 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
     for (int i = 0; i < NK; i++) s = E::dot(qv[i], tl.k[i], s);
 #pragma unroll
     for (int off = B; off < 64; off <<= 1) s += __shfl_xor(s, off);
-    s *= scale_log2e;
+    s *= a.scale_log2e;
     const int tok0 = blk * B;
     const bool valid = tok0 + t < ctx;
     s = valid ? s : -FLT_MAX;
@@ -280,7 +325,7 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
   // block n is consumed
   {
     Tile ta, tb;
-    int blk = wave;
+    int blk = blk_begin + wave;
     if (blk < nblk) load_tile(ta, table[blk]);
     while (blk < nblk) {
       int nb = blk + NW;
@@ -300,11 +345,11 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
   for (int off = 1; off < B; off <<= 1) l += __shfl_xor(l, off);
 #pragma unroll
   for (int i = 0; i < NV; i++) {
-    float a = acc[i];
+    float v = acc[i];
 #pragma unroll
-    for (int off = 1; off < VT; off <<= 1) a += __shfl_xor(a, off);
+    for (int off = 1; off < VT; off <<= 1) v += __shfl_xor(v, off);
     const int d = r + RPL * i;
-    if (tv == 0 && d < D) part_acc[wave][d] = a;
+    if (tv == 0 && d < D) part_acc[wave][d] = v;
   }
   if (lane == 0) {
     part_m[wave] = m;
@@ -312,71 +357,189 @@ pa_decode_kernel(typename E::storage* __restrict__ out, const typename E::storag
   }
   __syncthreads();
 
-  T* op = out + ((int64_t)seq * num_heads + head) * D;
-  for (int d = tid; d < D; d += NW * 64) {
-    float mg = part_m[0];
+  float mg = part_m[0];
 #pragma unroll
-    for (int w = 1; w < NW; w++) mg = fmaxf(mg, part_m[w]);
-    float L = 0.f, o = 0.f;
+  for (int w = 1; w < NW; w++) mg = fmaxf(mg, part_m[w]);
+  float f[NW];
+  float L = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; w++) {
-      const float f = fast_exp2(part_m[w] - mg);
-      L = __builtin_fmaf(part_l[w], f, L);
-      o = __builtin_fmaf(part_acc[w][d], f, o);
+  for (int w = 0; w < NW; w++) {
+    f[w] = fast_exp2(part_m[w] - mg);
+    L = __builtin_fmaf(part_l[w], f[w], L);
+  }
+  const int64_t row = (int64_t)seq * a.num_heads + head;
+  if (PART) {
+    const int64_t slot = row * a.num_parts + part;
+    for (int d = tid; d < D; d += NW * 64) {
+      float o = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) o = __builtin_fmaf(part_acc[w][d], f[w], o);
+      a.ws_acc[slot * D + d] = o;
     }
-    op[d] = E::from_float(o / (L + 1e-6f));
+    if (tid == 0) {
+      a.ws_ml[2 * slot] = mg;
+      a.ws_ml[2 * slot + 1] = L;
+    }
+  } else {
+    T* op = static_cast<T*>(a.out) + row * D;
+    const float inv = 1.f / (L + 1e-6f);
+    for (int d = tid; d < D; d += NW * 64) {
+      float o = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) o = __builtin_fmaf(part_acc[w][d], f[w], o);
+      op[d] = E::from_float(o * inv);
+    }
+  }
+}
+
+// Combines the partitions of one (sequence, head): one wave per output row.
+// The (max, sum) pairs are read one partition per lane and reduced across the
+// wave; the accumulator rows are then summed with lanes along d, all loads of
+// a group of partitions issued before the first use.
+template <typename E, int D>
+__global__ void __launch_bounds__(64) pa_decode_merge_kernel(const DecodeArgs a, const int tokens_per_part) {
+  typedef typename E::storage T;
+  constexpr int PER = (D + 63) / 64;
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;  // seq * num_heads + head
+  const int seq = (int)(row / a.num_heads);
+  const int ctx = a.context_lens[seq];
+  const int nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
+  const float* __restrict__ ml = a.ws_ml + 2 * row * a.num_parts;
+  const float* __restrict__ wacc = a.ws_acc + row * a.num_parts * D;
+
+  float mg = -FLT_MAX;
+  for (int p0 = 0; p0 < nparts; p0 += 64) {
+    const int p = p0 + lane;
+    float mp = p < nparts ? ml[2 * p] : -FLT_MAX;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mp = fmaxf(mp, __shfl_xor(mp, off));
+    mg = fmaxf(mg, mp);
+  }
+  float o[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) o[i] = 0.f;
+  float L = 0.f;
+  for (int p0 = 0; p0 < nparts; p0 += 64) {
+    const int p = p0 + lane;
+    const float fp = p < nparts ? fast_exp2(ml[2 * p] - mg) : 0.f;
+    float lp = p < nparts ? ml[2 * p + 1] * fp : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lp += __shfl_xor(lp, off);
+    L += lp;
+    const int n = min(64, nparts - p0);
+    for (int k0 = 0; k0 < n; k0 += 8) {
+      float v[8][PER];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+          const int d = lane + 64 * i;
+          v[k][i] = (k0 + k < n && d < D) ? wacc[(int64_t)(p0 + k0 + k) * D + d] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float f = __shfl(fp, (k0 + k) & 63);
+#pragma unroll
+        for (int i = 0; i < PER; i++) o[i] = __builtin_fmaf(v[k][i], f, o[i]);
+      }
+    }
+  }
+  const float inv = 1.f / (L + 1e-6f);
+  T* op = static_cast<T*>(a.out) + row * D;
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int d = lane + 64 * i;
+    if (d < D) op[d] = E::from_float(o[i] * inv);
   }
 }
 
 // ---- host side ----------------------------------------------------------------
 
+constexpr int kNumWaves = 4;
+
 template <typename E, int D, int B>
-static int launch(void* out, const void* q, const void* kc, const void* vc, float scale, const int32_t* bt,
-                  const int32_t* cl, int num_seqs, int num_heads, int max_blocks, int64_t q_stride,
-                  hipStream_t stream) {
-  typedef typename E::storage T;
-  constexpr int NW = 4;
-  const int q_vec_ok = aligned16(q) && ((q_stride * (int64_t)sizeof(T)) % 16 == 0) && ((D * sizeof(T)) % 16 == 0);
-  const float scale_log2e = scale * 1.4426950408889634f;
-  const unsigned grid = (unsigned)num_seqs * (unsigned)num_heads;
-  hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW>), dim3(grid), dim3(NW * 64), 0, stream,
-                     static_cast<T*>(out), static_cast<const T*>(q), static_cast<const T*>(kc),
-                     static_cast<const T*>(vc), scale_log2e, bt, cl, num_seqs, num_heads, max_blocks, q_stride,
-                     q_vec_ok);
-  PA_CHECK_LAUNCH("pa_decode_kernel launch");
+static int launch(const DecodeArgs& a, int tokens_per_part, hipStream_t stream) {
+  constexpr int NW = kNumWaves;
+  const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
+  if (a.num_parts <= 1) {
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, false>), dim3(rows), dim3(NW * 64), 0, stream, a);
+    PA_CHECK_LAUNCH("pa_decode_kernel launch");
+  } else {
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, true>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64), 0,
+                       stream, a);
+    PA_CHECK_LAUNCH("pa_decode_kernel (partitioned) launch");
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part);
+    PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
+  }
   return PA_OK;
 }
 
 template <typename E, int D>
-static int dispatch_block(int B, void* out, const void* q, const void* kc, const void* vc, float scale,
-                          const int32_t* bt, const int32_t* cl, int S, int H, int mb, int64_t qs, hipStream_t st) {
+static int dispatch_block(int B, const DecodeArgs& a, int tpp, hipStream_t st) {
   switch (B) {
-    case 8: return launch<E, D, 8>(out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
-    case 16: return launch<E, D, 16>(out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
-    case 32: return launch<E, D, 32>(out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
+    case 8: return launch<E, D, 8>(a, tpp, st);
+    case 16: return launch<E, D, 16>(a, tpp, st);
+    case 32: return launch<E, D, 32>(a, tpp, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported block size: %d (supported: 8, 16, 32)", B);
   }
 }
 
 template <typename E>
-static int dispatch_head(int D, int B, void* out, const void* q, const void* kc, const void* vc, float scale,
-                         const int32_t* bt, const int32_t* cl, int S, int H, int mb, int64_t qs, hipStream_t st) {
+static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, hipStream_t st) {
   switch (D) {
-    case 64: return dispatch_block<E, 64>(B, out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
-    case 80: return dispatch_block<E, 80>(B, out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
-    case 96: return dispatch_block<E, 96>(B, out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
-    case 128: return dispatch_block<E, 128>(B, out, q, kc, vc, scale, bt, cl, S, H, mb, qs, st);
+    case 64: return dispatch_block<E, 64>(B, a, tpp, st);
+    case 80: return dispatch_block<E, 80>(B, a, tpp, st);
+    case 96: return dispatch_block<E, 96>(B, a, tpp, st);
+    case 128: return dispatch_block<E, 128>(B, a, tpp, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported head size: %d (supported: 64, 80, 96, 128)", D);
   }
 }
 
-}  // namespace pa
+// Partition plan.  Splitting pays when the (sequence, head) rows alone cannot
+// fill the chip AND each row is a long serial chain of blocks: measured on
+// MI355X at 32 rows x 1024 tokens the split pair of kernels takes 10 us
+// against 13 us unsplit, at 128 rows there is no gain, and the gain grows with
+// the context length.  A partition is never shorter than one block per wave,
+// nor than 64 tokens.
+struct PartitionPlan {
+  int num_parts;
+  int blocks_per_part;
+};
 
-extern "C" int pa_single_query_cached_kv_attention(
-    void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
-    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
-    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* stream) {
-  using namespace pa;
+static PartitionPlan plan_partitions(int num_seqs, int num_heads, int block_size, int max_context_len) {
+  const int64_t rows = (int64_t)num_seqs * num_heads;
+  const int max_blocks = (max_context_len + block_size - 1) / block_size;
+  int min_blocks = kNumWaves;
+  while (min_blocks * block_size < 64) min_blocks *= 2;
+  PartitionPlan p = {1, max_blocks > 0 ? max_blocks : 1};
+  static const int forced = [] {
+    const char* e = getenv("PA_DECODE_FORCE_PARTS");  // tuning aid only
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t target_wgs = 1024;
+  const bool worth_it = rows <= 64 || (rows <= 256 && (int64_t)max_context_len * rows >= 256 * 1024);
+  int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
+  if (want <= 1 || max_blocks <= min_blocks) return p;
+  int bpp = (max_blocks + want - 1) / want;
+  if (bpp < min_blocks) bpp = min_blocks;
+  bpp = (bpp + kNumWaves - 1) / kNumWaves * kNumWaves;  // whole rounds of the waves
+  p.blocks_per_part = bpp;
+  p.num_parts = (max_blocks + bpp - 1) / bpp;
+  if (p.num_parts <= 1) p = PartitionPlan{1, max_blocks};
+  return p;
+}
+
+static size_t workspace_bytes_for(int64_t rows, int num_parts, int head_size) {
+  // accumulators [rows * parts][D] then (max, sum) pairs [rows * parts][2], fp32
+  return (size_t)rows * num_parts * (head_size + 2) * sizeof(float);
+}
+
+static int decode_entry(void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
+                        const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads,
+                        int head_size, int block_size, int max_num_blocks_per_seq, int max_context_len,
+                        int64_t q_stride, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
   clear_error();
   PA_REQUIRE(num_seqs >= 0 && num_heads >= 0, "negative num_seqs (%d) or num_heads (%d)", num_seqs, num_heads);
   if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
@@ -392,17 +555,72 @@ extern "C" int pa_single_query_cached_kv_attention(
              "block table width %d x block size %d cannot hold max_context_len %d", max_num_blocks_per_seq,
              block_size, max_context_len);
   PA_REQUIRE(aligned16(key_cache) && aligned16(value_cache), "key_cache / value_cache must be 16-byte aligned");
-  PA_REQUIRE((uint64_t)num_seqs * (uint64_t)num_heads < (1ull << 31), "num_seqs * num_heads too large");
+  const int64_t rows = (int64_t)num_seqs * num_heads;
+  PA_REQUIRE(rows < (1ll << 31), "num_seqs * num_heads too large");
+  const int es = elem_size(dtype);
+
+  DecodeArgs a;
+  a.out = out;
+  a.q = query;
+  a.k_cache = key_cache;
+  a.v_cache = value_cache;
+  a.block_tables = block_tables;
+  a.context_lens = context_lens;
+  a.ws_acc = nullptr;
+  a.ws_ml = nullptr;
+  a.q_stride = q_stride;
+  a.scale_log2e = scale * 1.4426950408889634f;
+  a.num_seqs = num_seqs;
+  a.num_heads = num_heads;
+  a.max_blocks_per_seq = max_num_blocks_per_seq;
+  a.q_vec_ok = aligned16(query) && ((q_stride * (int64_t)es) % 16 == 0) && ((head_size * es) % 16 == 0);
+  a.num_parts = 1;
+  a.blocks_per_part = max_num_blocks_per_seq;
+  if (workspace != nullptr) {
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
+    const PartitionPlan p = plan_partitions(num_seqs, num_heads, block_size, max_context_len);
+    if (p.num_parts > 1 && rows * p.num_parts < (1ll << 31) &&
+        workspace_bytes_for(rows, p.num_parts, head_size) <= workspace_bytes) {
+      a.num_parts = p.num_parts;
+      a.blocks_per_part = p.blocks_per_part;
+      a.ws_acc = static_cast<float*>(workspace);
+      a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
+    }
+  }
+  const int tokens_per_part = a.blocks_per_part * block_size;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case PA_DTYPE_F32:
-      return dispatch_head<ElemF32>(head_size, block_size, out, query, key_cache, value_cache, scale, block_tables,
-                                    context_lens, num_seqs, num_heads, max_num_blocks_per_seq, q_stride, st);
-    case PA_DTYPE_F16:
-      return dispatch_head<ElemF16>(head_size, block_size, out, query, key_cache, value_cache, scale, block_tables,
-                                    context_lens, num_seqs, num_heads, max_num_blocks_per_seq, q_stride, st);
-    default:
-      return dispatch_head<ElemBF16>(head_size, block_size, out, query, key_cache, value_cache, scale, block_tables,
-                                     context_lens, num_seqs, num_heads, max_num_blocks_per_seq, q_stride, st);
+    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, tokens_per_part, st);
+    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, tokens_per_part, st);
+    default: return dispatch_head<ElemBF16>(head_size, block_size, a, tokens_per_part, st);
   }
+}
+
+}  // namespace pa
+
+extern "C" int pa_single_query_cached_kv_attention(
+    void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
+    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* stream) {
+  return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
+                          head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, nullptr, 0,
+                          stream);
+}
+
+extern "C" size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size,
+                                            int max_context_len) {
+  if (num_seqs <= 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0 || max_context_len <= 0) return 0;
+  const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, block_size, max_context_len);
+  if (p.num_parts <= 1) return 0;
+  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p.num_parts, head_size);
+}
+
+extern "C" int pa_single_query_cached_kv_attention_ws(
+    void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
+    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* workspace,
+    size_t workspace_bytes, void* stream) {
+  return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
+                          head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
+                          workspace_bytes, stream);
 }
