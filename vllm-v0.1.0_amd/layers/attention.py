@@ -1,0 +1,140 @@
+"""Attention layer over the paged KV cache.
+
+Counterpart of PagedAttention (vllm/model_executor/layers/attention.py:16-156):
+same constructor, same `forward` arguments, same treatment of the flat token
+batch
+
+    |<-------------------- num_valid_tokens -------------------->|
+    |<----- num_prompt_tokens ----->|<-- num_generation_tokens -->|<-padding->|
+
+  1. prompt tokens: causal self-attention per prompt, no cache read (:115-122);
+  2. wait for the cache engine's swap of this layer (:125-126);
+  3. reshape_and_cache on [:num_valid_tokens] (:131-140);
+  4. single_query_cached_kv_attention on the generation tokens (:142-152).
+
+Steps 3 and 4 are the HIP operator modules.  Step 1 is outside the decode
+path: the reference uses xformers' CUTLASS kernel (:59-67); here it is torch's
+scaled_dot_product_attention per prompt.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..input_metadata import BlockDiagonalCausal, InputMetadata
+
+_SUPPORTED_HEAD_SIZES = [64, 80, 96, 128]
+
+
+class PagedAttention(nn.Module):
+
+    def __init__(self, num_heads: int, head_size: int, scale: float, attention_ops=None, cache_ops=None) -> None:
+        super().__init__()
+        if attention_ops is None or cache_ops is None:
+            from .. import attention_ops as _a, cache_ops as _c  # HIP modules; no fallback
+            attention_ops = attention_ops or _a
+            cache_ops = cache_ops or _c
+        self._attention_ops = attention_ops
+        self._cache_ops = cache_ops
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        if self.head_size not in _SUPPORTED_HEAD_SIZES:
+            raise ValueError(f"head_size ({self.head_size}) is not supported. "
+                             f"Supported head sizes: {_SUPPORTED_HEAD_SIZES}.")
+
+    def multi_query_kv_attention(
+        self,
+        output: torch.Tensor,   # [num_prompt_tokens, num_heads, head_size]
+        query: torch.Tensor,    # [num_prompt_tokens, num_heads, head_size]
+        key: torch.Tensor,
+        value: torch.Tensor,
+        attn_bias: BlockDiagonalCausal,
+    ) -> torch.Tensor:
+        for i in range(len(attn_bias.seqlens)):
+            lo, hi = attn_bias.cu_seqlens[i], attn_bias.cu_seqlens[i + 1]
+            # [n, H, D] -> [1, H, n, D]
+            q = query[lo:hi].transpose(0, 1).unsqueeze(0)
+            k = key[lo:hi].transpose(0, 1).unsqueeze(0)
+            v = value[lo:hi].transpose(0, 1).unsqueeze(0)
+            o = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=self.scale)
+            output[lo:hi].copy_(o.squeeze(0).transpose(0, 1))
+        return output
+
+    def single_query_cached_kv_attention(
+        self,
+        output: torch.Tensor,       # [num_generation_tokens, num_heads, head_size]
+        query: torch.Tensor,        # [num_generation_tokens, num_heads, head_size]
+        key_cache: torch.Tensor,    # [num_blocks, num_heads, head_size/x, block_size, x]
+        value_cache: torch.Tensor,  # [num_blocks, num_heads, head_size, block_size]
+        input_metadata: InputMetadata,
+    ) -> None:
+        block_size = value_cache.shape[3]
+        self._attention_ops.single_query_cached_kv_attention(
+            output,
+            query,
+            key_cache,
+            value_cache,
+            self.scale,
+            input_metadata.block_tables,
+            input_metadata.context_lens,
+            block_size,
+            input_metadata.max_context_len,
+        )
+
+    def forward(
+        self,
+        query: torch.Tensor,                  # [num_tokens, num_heads * head_size]
+        key: torch.Tensor,                    # [num_tokens, num_heads * head_size]
+        value: torch.Tensor,                  # [num_tokens, num_heads * head_size]
+        key_cache: Optional[torch.Tensor],
+        value_cache: Optional[torch.Tensor],
+        input_metadata: InputMetadata,
+        cache_event: Optional[torch.cuda.Event],
+    ) -> torch.Tensor:                        # [num_tokens, num_heads * head_size]
+        # query/key/value are column slices of the fused qkv projection: the
+        # views below keep their row stride.
+        query = query.view(-1, self.num_heads, self.head_size)
+        key = key.view(-1, self.num_heads, self.head_size)
+        value = value.view(-1, self.num_heads, self.head_size)
+        output = torch.empty(query.shape, dtype=query.dtype, device=query.device)
+
+        num_prompt_tokens = input_metadata.num_prompt_tokens
+        if num_prompt_tokens > 0:
+            self.multi_query_kv_attention(
+                output[:num_prompt_tokens],
+                query[:num_prompt_tokens],
+                key[:num_prompt_tokens],
+                value[:num_prompt_tokens],
+                input_metadata.attn_bias,
+            )
+
+        if cache_event is not None:
+            cache_event.wait()
+
+        num_valid_tokens = input_metadata.num_valid_tokens
+        if num_valid_tokens > 0 and key_cache is not None and value_cache is not None:
+            self._cache_ops.reshape_and_cache(
+                key[:num_valid_tokens],
+                value[:num_valid_tokens],
+                key_cache,
+                value_cache,
+                input_metadata.slot_mapping,
+            )
+
+        if input_metadata.num_generation_tokens > 0:
+            assert key_cache is not None and value_cache is not None, (
+                "key_cache and value_cache must be provided when generating tokens.")
+            self.single_query_cached_kv_attention(
+                output[num_prompt_tokens:num_valid_tokens],
+                query[num_prompt_tokens:num_valid_tokens],
+                key_cache,
+                value_cache,
+                input_metadata,
+            )
+
+        # the output may contain padding rows (left uninitialised, as in the reference)
+        return output.view(-1, self.num_heads * self.head_size)
