@@ -19,6 +19,7 @@ import __graft_entry__  # noqa: E402
 from bench import algorithmic_bytes  # noqa: E402
 
 USE_GRAPH = False
+SEQUENTIAL = False  # physical block i = logical block i (best case for DRAM page locality)
 DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
 
 
@@ -72,6 +73,8 @@ def run(cfg, pkg, device, launches=30):
     kcs = [torch.empty(NB, H, D // x, B, x, dtype=dt, device=device).normal_(0, 0.5) for _ in range(copies)]
     vcs = [torch.empty(NB, H, D, B, dtype=dt, device=device).normal_(0, 0.5) for _ in range(copies)]
     perm = torch.randperm(NB, generator=g).to(torch.int32)
+    if SEQUENTIAL:
+        perm = torch.arange(NB, dtype=torch.int32)
     bt = torch.zeros(S, bps, dtype=torch.int32)
     shared = perm[:groups * half].reshape(groups, half) if half else None
     own = perm[groups * half:].reshape(S, bps - half)
@@ -136,9 +139,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default="")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--sequential", action="store_true")
     args = ap.parse_args()
-    global USE_GRAPH
+    global USE_GRAPH, SEQUENTIAL
     USE_GRAPH = args.graph
+    SEQUENTIAL = args.sequential
     pkg = __graft_entry__.load_package()
     device = torch.device("cuda:0")
     rows = []

@@ -9,6 +9,30 @@
 
 namespace pa {
 
+// 16-byte cache-side stores carry the non-temporal hint.  Measured on MI355X:
+// after default-policy stores into a layer's cache, the next decode kernel over
+// that layer runs slower although only one token per sequence was written
+// (batch 256 x 32 heads x ctx 1024: 630 us untouched, +22 us after the 16-byte
+// K stores, +36 us after the 2-byte V stores, +53 us after both) — the first
+// read of lines a previous kernel left in the caches' write path is slow.
+// With the hint the stores go to memory and the penalty is gone.  Element-sized
+// stores keep the default policy: as non-temporal stores each of them becomes a
+// separate fabric write, which makes reshape_and_cache itself 4-6x slower
+// (51 vs 13 us for a decode step, 3.2 vs 0.5 ms for a 16k-token prompt).
+// 0 is kept as a build-time knob for A/B runs.
+#ifndef PA_CACHE_NT_STORE
+#define PA_CACHE_NT_STORE 1
+#endif
+
+template <typename W>
+__device__ __forceinline__ void store_cache(W* p, W v) {
+#if PA_CACHE_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <int BYTES> struct Word;
 template <> struct Word<1> { typedef uint8_t type; };
 template <> struct Word<2> { typedef uint16_t type; };
@@ -18,7 +42,9 @@ template <> struct Word<16> { typedef u32x4 type; };
 
 // ---- reshape_and_cache / gather_cached_kv ------------------------------------
 //
-// One workgroup per token.  The token's H*D elements are walked in 16-byte
+// grid = (tokens, slices of the token row): a decode step has only a few
+// hundred tokens, so each token's row is cut into slices of one workgroup's
+// width to put several workgroups on every CU.  The token's H*D elements are walked in 16-byte
 // vectors of X = 16/ES elements: a K vector is exactly one innermost [x] run
 // of the key cache (one 16-byte access on both sides); the X elements of a V
 // vector land B elements apart in the value cache (element-sized accesses on
@@ -30,7 +56,7 @@ template <> struct Word<16> { typedef u32x4 type; };
 // VEC = false is the element-wise fallback for token rows that are not
 // 16-byte aligned.
 template <int ES, bool GATHER, bool VEC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(128)
 pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __restrict__ key_cache,
                       char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_heads,
                       const int head_size, const int block_size, const int64_t key_stride_bytes,
@@ -50,7 +76,7 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
   if (VEC) {
     const int nvec = n / X;
     const int ndx = head_size / X;
-    for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nvec; i += gridDim.y * blockDim.x) {
       const int h = i / ndx;
       const int dx = i - h * ndx;
       // key cache [blk][h][dx][off][x]
@@ -64,9 +90,9 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
       if (!GATHER) {
         const u32x4 kv = *ktok;
         const u32x4 vv = *vtok;
-        *kc = kv;
         elem_t tmp[X];
         __builtin_memcpy(tmp, &vv, 16);
+        store_cache(kc, kv);
 #pragma unroll
         for (int e = 0; e < X; e++) vc[(int64_t)e * block_size] = tmp[e];
       } else {
@@ -81,7 +107,7 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
       }
     }
   } else {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
       const int h = i / head_size;
       const int d = i - h * head_size;
       const int64_t kc_el = cache_block + ((((int64_t)h * (head_size / X) + d / X) * block_size + off) * X) + d % X;
@@ -119,15 +145,20 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
   PA_REQUIRE((int64_t)num_heads * head_size < (1ll << 31), "%s: num_heads * head_size too large", what);
   const bool vec = aligned16(key) && aligned16(value) && (key_stride * es) % 16 == 0 && (value_stride * es) % 16 == 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nvec = num_heads * head_size / x;
-  int threads = vec ? nvec : num_heads * head_size;
-  threads = threads < 64 ? 64 : (threads > 256 ? 256 : (threads + 63) / 64 * 64);
+  const int work = vec ? num_heads * head_size / x : num_heads * head_size;
+  const int threads = work <= 64 ? 64 : 128;
+  int slices = (work + threads - 1) / threads;
+  // enough workgroups for ~8 per CU at small token counts, one slice per
+  // workgroup at most; large prompts already have one row per workgroup
+  const int want = (2048 + num_tokens - 1) / num_tokens;
+  if (slices > want) slices = want;
+  if (slices > 65535) slices = 65535;
   char* k = static_cast<char*>(key);
   char* v = static_cast<char*>(value);
   char* kc = static_cast<char*>(key_cache);
   char* vc = static_cast<char*>(value_cache);
 #define PA_LAUNCH_TOKEN(ES, VEC)                                                                              \
-  hipLaunchKernelGGL((pa_token_cache_kernel<ES, GATHER, VEC>), dim3(num_tokens), dim3(threads), 0, st, k, v, \
+  hipLaunchKernelGGL((pa_token_cache_kernel<ES, GATHER, VEC>), dim3(num_tokens, slices), dim3(threads), 0, st, k, v, \
                      kc, vc, slot_mapping, num_heads, head_size, block_size, key_stride * ES, value_stride * ES)
   if (es == 2) {
     if (vec) PA_LAUNCH_TOKEN(2, true); else PA_LAUNCH_TOKEN(2, false);
@@ -176,12 +207,12 @@ pa_copy_blocks_kernel(const CopyTable tab, const int64_t block_bytes, const int 
   // four independent 16-byte loads in flight per lane before the first store
   for (; i + 3 * 256 < hi; i += 4 * 256) {
     const word_t a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
-    d[i] = a;
-    d[i + 256] = b;
-    d[i + 512] = c;
-    d[i + 768] = e;
+    store_cache(&d[i], a);
+    store_cache(&d[i + 256], b);
+    store_cache(&d[i + 512], c);
+    store_cache(&d[i + 768], e);
   }
-  for (; i < hi; i += 256) d[i] = s[i];
+  for (; i < hi; i += 256) store_cache(&d[i], s[i]);
 }
 
 }  // namespace pa

@@ -29,6 +29,8 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pa_common.h"
 
 namespace pa {
@@ -155,22 +157,41 @@ struct DecodeArgs {
   int q_vec_ok;
   int num_parts;
   int blocks_per_part;
+  int group;  // sequences per work-order group (see the kernel)
 };
 
+// Build-time knob for A/B runs: 1 = stream every K/V tile with the
+// non-temporal hint, 0 = never, 2 (default) = per block, see load_tile.
 #ifndef PA_DECODE_NT
-#define PA_DECODE_NT 0
+#define PA_DECODE_NT 2
 #endif
 
+template <bool STREAM>
 __device__ __forceinline__ u32x4 load16(const char* p) {
-#if PA_DECODE_NT
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-#else
+  if (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
   return *reinterpret_cast<const u32x4*>(p);
+}
+
+// Build-time knob for A/B runs: minimum waves per SIMD asked of the register
+// allocator for the shapes whose two in-flight tiles take at most 64 VGPRs.
+// Default 1 = the compiler's own choice (138 VGPRs, 3 waves per SIMD at head
+// 128 / block 16); asking for 4 spills and measures 3-20 % slower.
+#ifndef PA_DECODE_LAST_DEFAULT
+#define PA_DECODE_LAST_DEFAULT(x) (x)
 #endif
+#ifndef PA_DECODE_MIN_WAVES
+#define PA_DECODE_MIN_WAVES 1
+#endif
+template <typename E, int D, int B>
+constexpr int decode_min_waves() {
+  constexpr int X = E::kX;
+  constexpr int NK = (D / X + 64 / B - 1) / (64 / B);
+  constexpr int NV = (D + 64 / (B / X) - 1) / (64 / (B / X));
+  return 2 * (NK + NV) * 4 <= 64 ? PA_DECODE_MIN_WAVES : 1;
 }
 
 template <typename E, int D, int B, int NW, bool PART>
-__global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) {
+__global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_decode_kernel(const DecodeArgs a) {
   typedef typename E::storage T;
   constexpr int X = E::kX;
   constexpr int NDX = D / X;
@@ -191,17 +212,30 @@ __global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // head-major work order: the workgroups of one XCD walk consecutive
-  // sequences of the same head, so sequences that share physical blocks
-  // (parallel sampling, beam search) meet in one L2.
+  // Work order.  The workgroups that share an XCD (and its L2) walk a
+  // contiguous range of work items ordered (group of G sequences, head,
+  // sequence in group):
+  //  * the G sequences of one head are neighbours in time and place, so
+  //    sequences that share physical blocks (parallel sampling, beam search)
+  //    read them together and meet in L2;
+  //  * G * num_heads is about the number of workgroups resident on an XCD, so
+  //    all heads are in flight at once.  A (block, head) tile sits at
+  //    (block * num_heads + head) * TILE_BYTES: with few heads in flight and
+  //    consecutive physical blocks, the loads would fall on a fraction of the
+  //    HBM channels (measured: 5.1 instead of 6.7 TB/s).
   unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
   int part = 0;
   if (PART) {
     part = work % (unsigned)a.num_parts;
     work /= (unsigned)a.num_parts;
   }
-  const int head = work / (unsigned)a.num_seqs;
-  const int seq = work - head * (unsigned)a.num_seqs;
+  const unsigned G = a.group;
+  const unsigned per_group = G * (unsigned)a.num_heads;
+  const unsigned grp = work / per_group;
+  const unsigned in_grp = work - grp * per_group;
+  const unsigned gsize = min(G, (unsigned)a.num_seqs - grp * G);  // the last group may be short
+  const int head = in_grp / gsize;
+  const int seq = grp * G + (in_grp - head * gsize);
 
   const int ctx = a.context_lens[seq];
   const int nblk_seq = (ctx + B - 1) / B;
@@ -211,6 +245,10 @@ __global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) 
   const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + a.blocks_per_part) : nblk_seq;
   if (PART && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
   const int* __restrict__ table = a.block_tables + (int64_t)seq * a.max_blocks_per_seq;
+  // Neighbouring sequences' tables, to spot shared physical blocks (forked
+  // sequences keep the parent's blocks and sit next to it in the batch).
+  const int* __restrict__ table_prev = table - (seq > 0 ? a.max_blocks_per_seq : 0);
+  const int* __restrict__ table_next = table + (seq + 1 < a.num_seqs ? a.max_blocks_per_seq : 0);
 
   const int t = lane % B, j = lane / B;
   const int tv = lane % VT, r = lane / VT;
@@ -247,14 +285,15 @@ __global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) 
   };
 
   // lane l reads bytes [l*16, l*16+16) of every 1 KiB slice of the tile: for K
-  // that is (dx = j + KJ*i, token t), for V (row r + RPL*i, token vector tv)
-  auto load_tile = [&](Tile& tl, int phys) {
+  // that is (dx = j + KJ*i, token t), for V (row r + RPL*i, token vector tv).
+  auto load_tile_as = [&](Tile& tl, int phys, auto stream_tag) {
+    constexpr bool STREAM = decltype(stream_tag)::value;
     const char* kp = kbase + (int64_t)phys * block_stride;
     const char* vp = vbase + (int64_t)phys * block_stride;
 #pragma unroll
     for (int i = 0; i < NK; i++) {
       if ((NDX % KJ == 0) || (j + KJ * i < NDX)) {
-        tl.k[i] = load16(kp + i * 1024);
+        tl.k[i] = load16<STREAM>(kp + i * 1024);
       } else {
         tl.k[i] = u32x4{0u, 0u, 0u, 0u};
       }
@@ -262,11 +301,67 @@ __global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) 
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       if ((D % RPL == 0) || (r + RPL * i < D)) {
-        tl.v[i] = load16(vp + i * 1024);
+        tl.v[i] = load16<STREAM>(vp + i * 1024);
       } else {
         tl.v[i] = u32x4{0u, 0u, 0u, 0u};
       }
     }
+  };
+  // Load policy per block.  A block read by this sequence only is streamed
+  // with the non-temporal hint: it is used once, and keeping it out of the
+  // caches' retention is worth +11 % bandwidth on MI355X.  A block that a
+  // neighbouring sequence also maps at the same position is loaded with the
+  // default policy so that the second reader hits L2.  (Entries of a
+  // neighbour's table past its own context are padding; a false match only
+  // costs the hint.)
+  // Block-table entries of this wave, 64 at a time, one per lane: lane i
+  // holds the entry of the wave's (chunk * 64 + i)-th block, i.e. logical block
+  // blk_begin + wave + NW * (chunk * 64 + i).  The loop picks its entry with
+  // v_readlane, so no memory operation sits between a tile's block number and
+  // its loads.  Bit 31 of an entry = "a neighbouring sequence maps the same
+  // physical block at this position".
+  int entries = 0;
+  auto fetch_entries = [&](int it0) {
+    const int b = blk_begin + wave + NW * (it0 + lane);
+    int e = 0;
+    if (b < nblk) {
+      const int phys = table[b];
+      e = phys;
+#if PA_DECODE_NT == 2
+      // the sequence's last block was written a moment ago by
+      // reshape_and_cache (the new token): streaming loads of just-written
+      // lines measured 8 % slower for the whole kernel, so it is read with the
+      // default policy like a shared block
+      const bool shared = (table_prev != table && table_prev[b] == phys) ||
+                          (table_next != table && table_next[b] == phys) || PA_DECODE_LAST_DEFAULT(b == nblk_seq - 1);
+      e |= shared ? (int)0x80000000 : 0;
+#endif
+    }
+    entries = e;
+  };
+  // entry of the wave's it-th block (it is wave-uniform)
+  auto entry = [&](int it) -> int {
+    if ((it & 63) == 0) fetch_entries(it);
+    return __builtin_amdgcn_readlane(entries, it & 63);
+  };
+  auto load_tile = [&](Tile& tl, int e) {
+    const int phys = e & 0x7fffffff;
+#if PA_DECODE_NT == 1
+    load_tile_as(tl, phys, std::true_type{});
+#elif PA_DECODE_NT == 0
+    load_tile_as(tl, phys, std::false_type{});
+#else
+    // The two arms differ only in the loads' cache-policy bit; the markers
+    // keep the compiler from hoisting or sinking the loads into one common
+    // copy without the hint.
+    if (e < 0) {
+      load_tile_as(tl, phys, std::false_type{});
+    } else {
+      asm volatile("; streamed tile" ::: "memory");
+      load_tile_as(tl, phys, std::true_type{});
+      asm volatile("; end of streamed tile" ::: "memory");
+    }
+#endif
   };
 
   float m = -FLT_MAX;  // running maximum (log2 domain)
@@ -321,22 +416,25 @@ __global__ void __launch_bounds__(NW * 64) pa_decode_kernel(const DecodeArgs a) 
     for (int i = 0; i < NV; i++) acc[i] = E::pv(pvv, tl.v[i], acc[i] * alpha);
   };
 
-  // two register tiles, alternating: the loads of block n+1 are issued before
-  // block n is consumed
+  // Two register tiles, alternating: the loads of block n+1 are issued before
+  // block n is consumed.
   {
     Tile ta, tb;
     int blk = blk_begin + wave;
-    if (blk < nblk) load_tile(ta, table[blk]);
+    int it = 0;  // index of blk among this wave's blocks
+    if (blk < nblk) load_tile(ta, entry(0));
     while (blk < nblk) {
       int nb = blk + NW;
-      if (nb < nblk) load_tile(tb, table[nb]);
+      if (nb < nblk) load_tile(tb, entry(it + 1));
       consume(ta, blk);
       blk = nb;
+      it++;
       if (blk >= nblk) break;
       nb = blk + NW;
-      if (nb < nblk) load_tile(ta, table[nb]);
+      if (nb < nblk) load_tile(ta, entry(it + 1));
       consume(tb, blk);
       blk = nb;
+      it++;
     }
   }
 
@@ -506,6 +604,7 @@ static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, hipStream_t
 struct PartitionPlan {
   int num_parts;
   int blocks_per_part;
+  int group;  // sequences per work-order group (see the kernel)
 };
 
 static PartitionPlan plan_partitions(int num_seqs, int num_heads, int block_size, int max_context_len) {
@@ -576,6 +675,9 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.q_vec_ok = aligned16(query) && ((q_stride * (int64_t)es) % 16 == 0) && ((head_size * es) % 16 == 0);
   a.num_parts = 1;
   a.blocks_per_part = max_num_blocks_per_seq;
+  // ~128 workgroups are resident per XCD (32 CUs x 4): G * num_heads of them
+  // should span every head
+  a.group = 128 / num_heads < 1 ? 1 : (128 / num_heads > 16 ? 16 : 128 / num_heads);
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     const PartitionPlan p = plan_partitions(num_seqs, num_heads, block_size, max_context_len);
