@@ -39,12 +39,4 @@ for _ in range(3): dec(0)
 torch.cuda.synchronize()
 measure("A decode alone", lambda l: None)
 measure("B reshape(same layer) then decode", lambda l: rsh(l))
-sink = torch.zeros(1, device=dev)
-def rsh_then_read_v(l):
-    rsh(l)
-    sink.add_(vcs[l][last, :, :, 15].float().sum())
-measure("R reshape; read back the written V elements; decode", rsh_then_read_v)
-def rsh_then_read_tiles(l):
-    rsh(l)
-    sink.add_(vcs[l][last].float().sum())
-measure("S reshape; read back whole last V tiles; decode", rsh_then_read_tiles)
+

@@ -176,9 +176,6 @@ __device__ __forceinline__ u32x4 load16(const char* p) {
 // allocator for the shapes whose two in-flight tiles take at most 64 VGPRs.
 // Default 1 = the compiler's own choice (138 VGPRs, 3 waves per SIMD at head
 // 128 / block 16); asking for 4 spills and measures 3-20 % slower.
-#ifndef PA_DECODE_LAST_DEFAULT
-#define PA_DECODE_LAST_DEFAULT(x) (x)
-#endif
 #ifndef PA_DECODE_MIN_WAVES
 #define PA_DECODE_MIN_WAVES 1
 #endif
@@ -328,12 +325,8 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
       const int phys = table[b];
       e = phys;
 #if PA_DECODE_NT == 2
-      // the sequence's last block was written a moment ago by
-      // reshape_and_cache (the new token): streaming loads of just-written
-      // lines measured 8 % slower for the whole kernel, so it is read with the
-      // default policy like a shared block
       const bool shared = (table_prev != table && table_prev[b] == phys) ||
-                          (table_next != table && table_next[b] == phys) || PA_DECODE_LAST_DEFAULT(b == nblk_seq - 1);
+                          (table_next != table && table_next[b] == phys);
       e |= shared ? (int)0x80000000 : 0;
 #endif
     }
