@@ -168,6 +168,42 @@ int pa_swap_blocks(
     const void* src, void* dst, const int64_t* block_pairs, int num_pairs,
     int64_t block_bytes, int kind, void* stream);
 
+/* ---- operators next to the attention path in a decoder layer ------------- */
+
+/*
+ * GPT-NeoX style rotary embedding, in place on query and key.  Replaces
+ * rotary_embedding_neox (csrc/pos_encoding_kernels.cu:51-83; kernel :7-47).
+ *
+ *   positions      [num_tokens] int64
+ *   query, key     [num_tokens, num_heads * head_size], row strides in elements
+ *   cos_sin_cache  [max_position, rot_dim] = cos(rot_dim/2) | sin(rot_dim/2) per row
+ *
+ * Only the first rot_dim elements of each head are rotated (rot_dim <= head_size,
+ * even).  Arithmetic is done in the storage type, one rounding per operation, as
+ * the reference's kernel does.
+ */
+int pa_rotary_embedding_neox(
+    const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+    int num_tokens, int num_heads, int head_size, int rot_dim,
+    int64_t query_stride, int64_t key_stride, int dtype, void* stream);
+
+/*
+ * out = ((T)(x * rsqrt(mean(x^2) + epsilon))) * weight per row.  Replaces
+ * rms_norm (csrc/layernorm_kernels.cu:38-63; kernel :10-34).  out, input:
+ * [num_tokens, hidden_size] dense; weight: [hidden_size].
+ */
+int pa_rms_norm(
+    void* out, const void* input, const void* weight, float epsilon,
+    int num_tokens, int hidden_size, int dtype, void* stream);
+
+/*
+ * out[t, i] = silu(input[t, i]) * input[t, d + i].  Replaces silu_and_mul
+ * (csrc/activation_kernels.cu:27-48; kernel :13-23).  input: [num_tokens, 2 * d]
+ * dense; out: [num_tokens, d] dense.
+ */
+int pa_silu_and_mul(
+    void* out, const void* input, int num_tokens, int d, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,3 +273,97 @@ def make_cache_inputs(case: CacheCase) -> Dict[str, object]:
     dst = perm[M:2 * M]
     return {"qkv": qkv, "key_caches": kcs, "value_caches": vcs, "slot_mapping": slots,
             "src_blocks": src.astype(np.int64), "dst_blocks": dst.astype(np.int64)}
+
+
+# ---- element-wise operator cases (rotary embedding, RMS norm, SiLU-and-mul) --
+
+@dataclass
+class ElementwiseCase:
+    name: str
+    op: str                 # "rotary" | "rms_norm" | "silu_and_mul"
+    dtype: str = "float16"
+    num_tokens: int = 7
+    num_heads: int = 3      # rotary
+    head_size: int = 64     # rotary
+    rot_dim: int = 64       # rotary
+    max_position: int = 64  # rotary
+    hidden: int = 64        # rms_norm: hidden size; silu_and_mul: d
+    weight: str = "uniform1e-3"  # rms_norm: the reference test's weights, or "normal1" = N(1, 0.1)
+    seed: int = 0
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), sort_keys=True)
+
+
+def cos_sin_cache(max_position: int, rot_dim: int, dtype: str, base: float = 10000.0) -> np.ndarray:
+    """[max_position, rot_dim] = cos | sin of position * base^(-2i/rot_dim), the
+    table PagedAttentionWithRoPE registers
+    (vllm/model_executor/layers/attention.py:173-186)."""
+    inv_freq = 1.0 / (base ** (np.arange(0, rot_dim, 2, dtype=np.float64) / rot_dim))
+    freqs = np.arange(max_position, dtype=np.float64)[:, None] * inv_freq[None, :]
+    return to_storage(np.concatenate([np.cos(freqs), np.sin(freqs)], axis=-1), dtype)
+
+
+def make_elementwise_inputs(case: ElementwiseCase) -> Dict[str, np.ndarray]:
+    base = case.seed * 1000 + 700
+    T = case.num_tokens
+    if case.op == "rotary":
+        n = case.num_heads * case.head_size
+        return {
+            "positions": randint(T, base + 1, 0, case.max_position - 1),
+            "query": to_storage(normal(T * n, base + 2), case.dtype).reshape(T, n),
+            "key": to_storage(normal(T * n, base + 3), case.dtype).reshape(T, n),
+            "cos_sin_cache": cos_sin_cache(case.max_position, case.rot_dim, case.dtype),
+        }
+    if case.op == "rms_norm":
+        if case.weight == "uniform1e-3":
+            w = uniform(case.hidden, base + 2, -1e-3, 1e-3)
+        else:
+            w = 1.0 + normal(case.hidden, base + 2, 0.1)
+        return {
+            "input": to_storage(normal(T * case.hidden, base + 1), case.dtype).reshape(T, case.hidden),
+            "weight": to_storage(w, case.dtype),
+        }
+    if case.op == "silu_and_mul":
+        return {"input": to_storage(normal(T * 2 * case.hidden, base + 1, 2.0), case.dtype).reshape(T, 2 * case.hidden)}
+    raise ValueError(case.op)
+
+
+def checksum_arrays(arrays: Dict[str, np.ndarray]) -> str:
+    h = hashlib.sha256()
+    for k in sorted(arrays):
+        a = np.ascontiguousarray(arrays[k])
+        h.update(k.encode())
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def elementwise_cases() -> List[ElementwiseCase]:
+    cases: List[ElementwiseCase] = []
+    seed = 300
+    for dtype in DTYPES:
+        # tests/kernels/test_pos_encoding.py:136-146: 8 head sizes, rot_dim = head size, 5 heads
+        for hs in (32, 64, 80, 96, 128, 160, 192, 256):
+            cases.append(ElementwiseCase(name=f"rotary_{dtype}_h{hs}", op="rotary", dtype=dtype, num_tokens=19,
+                                         num_heads=5, head_size=hs, rot_dim=hs, max_position=64, seed=seed))
+            seed += 1
+        # partial rotary (GPT-NeoX rotary_pct, vllm/model_executor/models/gpt_neox.py:64) and a
+        # rot_dim whose half is not a multiple of a 16-byte vector
+        for hs, rd in ((96, 24), (128, 32), (64, 20)):
+            cases.append(ElementwiseCase(name=f"rotary_{dtype}_h{hs}_r{rd}", op="rotary", dtype=dtype, num_tokens=11,
+                                         num_heads=3, head_size=hs, rot_dim=rd, max_position=64, seed=seed))
+            seed += 1
+        # tests/kernels/test_layernorm.py:46-57
+        for hidden in (13, 64, 1024, 5120):
+            for w in ("uniform1e-3", "normal1"):
+                cases.append(ElementwiseCase(name=f"rms_{dtype}_{hidden}_{w}", op="rms_norm", dtype=dtype,
+                                             num_tokens=7, hidden=hidden, weight=w, seed=seed))
+                seed += 1
+        # tests/kernels/test_activation.py:27-33 (smaller d, plus one that is not a multiple of 8)
+        for d in (512, 1001, 5120):
+            cases.append(ElementwiseCase(name=f"silu_{dtype}_{d}", op="silu_and_mul", dtype=dtype, num_tokens=7,
+                                         hidden=d, seed=seed))
+            seed += 1
+    return cases

@@ -419,3 +419,73 @@ int pao_swap_blocks(const void* src, void* dst, const int64_t* pairs,
   }
   return 0;
 }
+
+/* ---- element-wise operators next to the attention path ------------------
+ *
+ * Each follows its reference kernel's rounding points: arithmetic on 16-bit
+ * types rounds to the storage type after every operation (the reference's
+ * c10::Half / BFloat16 operators do), fp32 stays fp32.
+ */
+
+/* rotary_embedding_neox_kernel, csrc/pos_encoding_kernels.cu:7-47, in place */
+int pao_rotary_embedding_neox(const int64_t* positions, void* query, void* key,
+                              const void* cos_sin_cache, int num_tokens,
+                              int num_heads, int head_size, int rot_dim,
+                              int64_t query_stride, int64_t key_stride, int dtype) {
+  if (rot_dim % 2 || rot_dim > head_size) return 1;
+  const int embed = rot_dim / 2;
+  for (int t = 0; t < num_tokens; t++) {
+    const int64_t cbase = positions[t] * rot_dim;
+    for (int w = 0; w < 2; w++) {
+      void* buf = w == 0 ? query : key;
+      const int64_t row = (int64_t)t * (w == 0 ? query_stride : key_stride);
+      for (int h = 0; h < num_heads; h++) {
+        for (int i = 0; i < embed; i++) {
+          const float c = pao_load(cos_sin_cache, cbase + i, dtype);
+          const float s = pao_load(cos_sin_cache, cbase + embed + i, dtype);
+          const int64_t xi = row + (int64_t)h * head_size + i, yi = xi + embed;
+          const float x = pao_load(buf, xi, dtype), y = pao_load(buf, yi, dtype);
+          const float ox = pao_round_to(pao_round_to(x * c, dtype) - pao_round_to(y * s, dtype), dtype);
+          const float oy = pao_round_to(pao_round_to(y * c, dtype) + pao_round_to(x * s, dtype), dtype);
+          pao_store(buf, xi, dtype, ox);
+          pao_store(buf, yi, dtype, oy);
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* rms_norm_kernel, csrc/layernorm_kernels.cu:10-34 (variance summed in double
+ * here: the reference's fp32 block reduction has no fixed order) */
+int pao_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                 int num_tokens, int hidden_size, int dtype) {
+  for (int t = 0; t < num_tokens; t++) {
+    const int64_t row = (int64_t)t * hidden_size;
+    double ss = 0.0;
+    for (int i = 0; i < hidden_size; i++) {
+      const double x = pao_load(input, row + i, dtype);
+      ss += x * x;
+    }
+    const float s = (float)(1.0 / sqrt(ss / hidden_size + (double)epsilon));
+    for (int i = 0; i < hidden_size; i++) {
+      const float x = pao_load(input, row + i, dtype);
+      const float n = pao_round_to(x * s, dtype);
+      pao_store(out, row + i, dtype, n * pao_load(weight, i, dtype));
+    }
+  }
+  return 0;
+}
+
+/* silu_and_mul_kernel, csrc/activation_kernels.cu:6-23 */
+int pao_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype) {
+  for (int t = 0; t < num_tokens; t++) {
+    for (int i = 0; i < d; i++) {
+      const float x = pao_load(input, (int64_t)t * 2 * d + i, dtype);
+      const float y = pao_load(input, (int64_t)t * 2 * d + d + i, dtype);
+      const float silu = pao_round_to(x / (1.0f + expf(-x)), dtype);
+      pao_store(out, (int64_t)t * d + i, dtype, silu * y);
+    }
+  }
+  return 0;
+}

@@ -47,6 +47,12 @@ def lib() -> ctypes.CDLL:
         L.pao_copy_blocks.restype = i32
         L.pao_swap_blocks.argtypes = [vp, vp, vp, i32, i64]
         L.pao_swap_blocks.restype = i32
+        L.pao_rotary_embedding_neox.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32]
+        L.pao_rotary_embedding_neox.restype = i32
+        L.pao_rms_norm.argtypes = [vp, vp, vp, f32, i32, i32, i32]
+        L.pao_rms_norm.restype = i32
+        L.pao_silu_and_mul.argtypes = [vp, vp, i32, i32, i32]
+        L.pao_silu_and_mul.restype = i32
         L.pao_test_half_to_float.argtypes = [ctypes.c_uint16]
         L.pao_test_half_to_float.restype = f32
         L.pao_test_float_to_half.argtypes = [f32]
@@ -163,3 +169,41 @@ def swap_blocks(src_cache: np.ndarray, dst_cache: np.ndarray,
                                src_cache[0].nbytes)
     if rc != 0:
         raise RuntimeError(f"pa_oracle swap_blocks failed with code {rc}")
+
+
+def rotary_embedding_neox(positions: np.ndarray, query: np.ndarray, key: np.ndarray, head_size: int,
+                          cos_sin_cache: np.ndarray, dtype: str) -> None:
+    """In place on query / key ([T, H * D] arrays, row stride free)."""
+    T = query.shape[0]
+    positions = np.ascontiguousarray(positions, dtype=np.int64)
+    assert cos_sin_cache.flags.c_contiguous
+    assert query.strides[1] == query.itemsize and key.strides[1] == key.itemsize
+    if T == 0:
+        return
+    rc = lib().pao_rotary_embedding_neox(
+        _ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), T, query.shape[1] // head_size, head_size,
+        cos_sin_cache.shape[1], _elem_stride(query, 0), _elem_stride(key, 0), DTYPE_CODE[dtype])
+    if rc != 0:
+        raise RuntimeError(f"pa_oracle rotary_embedding_neox failed with code {rc}")
+
+
+def rms_norm(input: np.ndarray, weight: np.ndarray, epsilon: float, dtype: str) -> np.ndarray:
+    assert input.flags.c_contiguous and weight.flags.c_contiguous
+    out = np.zeros_like(input)
+    if input.size:
+        rc = lib().pao_rms_norm(_ptr(out), _ptr(input), _ptr(weight), float(epsilon), input.shape[0],
+                                input.shape[1], DTYPE_CODE[dtype])
+        if rc != 0:
+            raise RuntimeError(f"pa_oracle rms_norm failed with code {rc}")
+    return out
+
+
+def silu_and_mul(input: np.ndarray, dtype: str) -> np.ndarray:
+    assert input.flags.c_contiguous
+    T, d2 = input.shape
+    out = np.zeros((T, d2 // 2), dtype=input.dtype)
+    if out.size:
+        rc = lib().pao_silu_and_mul(_ptr(out), _ptr(input), T, d2 // 2, DTYPE_CODE[dtype])
+        if rc != 0:
+            raise RuntimeError(f"pa_oracle silu_and_mul failed with code {rc}")
+    return out

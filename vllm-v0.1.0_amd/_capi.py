@@ -34,6 +34,9 @@ EXPORTS = (
     "pa_gather_cached_kv",
     "pa_copy_blocks",
     "pa_swap_blocks",
+    "pa_rotary_embedding_neox",
+    "pa_rms_norm",
+    "pa_silu_and_mul",
 )
 
 
@@ -72,6 +75,12 @@ def _load() -> ctypes.CDLL:
     lib.pa_copy_blocks.restype = i32
     lib.pa_swap_blocks.argtypes = [vp, vp, vp, i32, i64, i32, vp]
     lib.pa_swap_blocks.restype = i32
+    lib.pa_rotary_embedding_neox.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
+    lib.pa_rotary_embedding_neox.restype = i32
+    lib.pa_rms_norm.argtypes = [vp, vp, vp, f32, i32, i32, i32, vp]
+    lib.pa_rms_norm.restype = i32
+    lib.pa_silu_and_mul.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.pa_silu_and_mul.restype = i32
     if lib.pa_abi_version() != PA_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.pa_abi_version()} != {PA_ABI_VERSION}")
     return lib
@@ -184,4 +193,25 @@ def swap_blocks(src_cache, dst_cache, src: Sequence[int], dst: Sequence[int], st
     block_bytes = src_cache[0].numel() * src_cache.element_size()
     rc = lib.pa_swap_blocks(src_cache.data_ptr(), dst_cache.data_ptr(), _pairs(src, dst), len(src),
                             block_bytes, kind, _stream_handle(stream))
+    check(rc)
+
+
+def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache, stream=None) -> None:
+    T = query.shape[0]
+    rc = lib.pa_rotary_embedding_neox(
+        positions.data_ptr(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(), T,
+        query.shape[1] // head_size, head_size, cos_sin_cache.shape[1], query.stride(0) if T > 0 else 0,
+        key.stride(0) if T > 0 else 0, dtype_code(query.dtype), _stream_handle(stream))
+    check(rc)
+
+
+def rms_norm(out, input, weight, epsilon, stream=None) -> None:
+    rc = lib.pa_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon), input.shape[0],
+                         input.shape[1], dtype_code(input.dtype), _stream_handle(stream))
+    check(rc)
+
+
+def silu_and_mul(out, input, stream=None) -> None:
+    rc = lib.pa_silu_and_mul(out.data_ptr(), input.data_ptr(), input.shape[0], input.shape[1] // 2,
+                             dtype_code(input.dtype), _stream_handle(stream))
     check(rc)
