@@ -154,3 +154,89 @@ def test_cache_engine_swap_out_swap_in_and_copy(pkg):
                 assert torch.equal(engine.gpu_cache[l][0][d], before[l][0][s])
                 assert torch.equal(engine.gpu_cache[l][1][d], before[l][1][s])
         assert torch.equal(engine.gpu_cache[l][0][8], before[l][0][8])
+
+
+def test_rope_attention_rmsnorm_swiglu_layers_over_decode_steps(pkg):
+    """A LLaMA-shaped slice of one decoder layer (llama.py:88-131, 56-81):
+    RMSNorm -> qkv -> PagedAttentionWithRoPE -> gate/up -> SiluAndMul, one
+    prompt step and 20 decode steps for two sequences, against the same
+    arithmetic in fp32 torch with dense attention over the rotated history."""
+    import torch
+    from vllm_amd.layers import PagedAttentionWithRoPE, RMSNorm, SiluAndMul
+    from vllm_amd.worker import prepare_inputs
+
+    dtype = torch.float16
+    H, D, B, hidden, inter = 4, 128, 16, 512, 768
+    scale = D ** -0.5
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)  # the cos/sin table takes the default dtype (attention.py:181-184)
+    try:
+        attn = PagedAttentionWithRoPE(H, D, scale, rotary_dim=D, max_position=256).to(DEV)
+    finally:
+        torch.set_default_dtype(old)
+    assert attn.cos_sin_cache.dtype == dtype and attn.cos_sin_cache.shape == (256, D)
+    norm = RMSNorm(hidden).to(DEV).to(dtype)
+    norm.weight.data.copy_(1 + 0.1 * torch.randn(hidden, device=DEV, generator=g))
+    act = SiluAndMul()
+    w_qkv = (torch.randn(hidden, 3 * H * D, device=DEV, generator=g) * hidden ** -0.5).to(dtype)
+    w_gu = (torch.randn(H * D, 2 * inter, device=DEV, generator=g) * (H * D) ** -0.5).to(dtype)
+    kc = torch.full((32, H, D // 8, B, 8), float("nan"), dtype=dtype, device=DEV)
+    vc = torch.full((32, H, D, B), float("nan"), dtype=dtype, device=DEV)
+
+    def rotate(x, pos):  # x [n, H, D] fp32, NeoX pairing (i, i + D/2)
+        cs = attn.cos_sin_cache[pos].float()
+        c, s = cs[:, None, : D // 2], cs[:, None, D // 2:]
+        x1, x2 = x[..., : D // 2], x[..., D // 2:]
+        return torch.cat((x1 * c - x2 * s, x2 * c + x1 * s), dim=-1)
+
+    seqs = {0: SeqData(range(7)), 1: SeqData(range(50, 50 + 21))}
+    tables = {0: [9, 3], 1: [17, 4, 11]}
+    hist = {0: ([], []), 1: ([], [])}
+
+    def step(is_prompt):
+        groups = [SimpleNamespace(request_id=str(i), is_prompt=is_prompt, seq_data={i: seqs[i]},
+                                  sampling_params=None, block_tables={i: tables[i]}) for i in seqs]
+        _, positions, meta = prepare_inputs(groups, B, device=DEV)
+        n = positions.shape[0]
+        x = torch.randn(n, hidden, dtype=dtype, device=DEV, generator=g)
+        h = norm(x)
+        h_ref = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6)).to(dtype) * norm.weight.data
+        assert torch.allclose(h, h_ref, atol=1e-3, rtol=1e-3)
+        qkv = h @ w_qkv
+        q, k, v = qkv.chunk(3, dim=-1)
+        q0, k0 = q.clone().float().view(n, H, D), k.clone().float().view(n, H, D)
+        o = attn(positions, q, k, v, kc, vc, meta, None)
+        y = act(o @ w_gu)
+        torch.cuda.synchronize()
+        qr, kr = rotate(q0, positions), rotate(k0, positions)
+        assert torch.allclose(q.float().view(n, H, D), qr, atol=2e-3, rtol=2e-3)  # rotated in place
+        rows = []
+        if is_prompt:
+            r = 0
+            for i in seqs:
+                for t in range(seqs[i].get_len()):
+                    rows.append((r, i))
+                    r += 1
+        else:
+            rows = [(r, i) for r, i in enumerate(seqs)]
+        v3 = v.float().view(n, H, D)
+        for r, i in rows:
+            hist[i][0].append(kr[r])
+            hist[i][1].append(v3[r])
+            upto = positions[r].item() + 1
+            want = _dense_attention(qr[r], torch.stack(hist[i][0][:upto]), torch.stack(hist[i][1][:upto]), scale)
+            assert torch.allclose(o.float().view(n, H, D)[r], want, atol=3e-3, rtol=3e-3), (is_prompt, r, i)
+        valid = [r for r, _ in rows]
+        gu = (o @ w_gu).float()[valid]
+        want_y = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        assert torch.allclose(y.float()[valid], want_y, atol=2e-3, rtol=2e-3)
+
+    step(True)
+    for s in range(20):
+        for i in seqs:
+            seqs[i].tokens.append(900 + s)
+            if seqs[i].get_len() > len(tables[i]) * B:
+                tables[i].append(20 + i * 5 + len(tables[i]))
+        step(False)

@@ -1,1 +1,3 @@
-from .attention import PagedAttention  # noqa: F401
+from .activation import SiluAndMul  # noqa: F401
+from .attention import PagedAttention, PagedAttentionWithRoPE  # noqa: F401
+from .layernorm import RMSNorm  # noqa: F401

@@ -138,3 +138,37 @@ class PagedAttention(nn.Module):
 
         # the output may contain padding rows (left uninitialised, as in the reference)
         return output.view(-1, self.num_heads * self.head_size)
+
+
+class PagedAttentionWithRoPE(PagedAttention):
+    """PagedAttention preceded by the GPT-NeoX rotary embedding of query and key
+    (vllm/model_executor/layers/attention.py:159-215): same constructor, same
+    cos/sin table ([max_position, rotary_dim], cos half then sin half, in the
+    default dtype), same `forward` arguments."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float, rotary_dim: int,
+                 max_position: int = 8192, base: int = 10000, attention_ops=None, cache_ops=None,
+                 pos_encoding_ops=None) -> None:
+        super().__init__(num_heads, head_size, scale, attention_ops, cache_ops)
+        if pos_encoding_ops is None:
+            from .. import pos_encoding_ops  # HIP module; no fallback
+        self._pos_encoding_ops = pos_encoding_ops
+        inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2) / rotary_dim))
+        freqs = torch.outer(torch.arange(max_position).float(), inv_freq.float())
+        table = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(torch.get_default_dtype())
+        self.register_buffer("cos_sin_cache", table, persistent=False)
+
+    def forward(
+        self,
+        positions: torch.Tensor,              # [num_tokens]
+        query: torch.Tensor,                  # [num_tokens, num_heads * head_size]
+        key: torch.Tensor,
+        value: torch.Tensor,
+        key_cache: Optional[torch.Tensor],
+        value_cache: Optional[torch.Tensor],
+        input_metadata: InputMetadata,
+        cache_event: Optional[torch.cuda.Event],
+    ) -> torch.Tensor:
+        # in place on the q and k column slices of the fused qkv row
+        self._pos_encoding_ops.rotary_embedding_neox(positions, query, key, self.head_size, self.cos_sin_cache)
+        return super().forward(query, key, value, key_cache, value_cache, input_metadata, cache_event)
