@@ -168,6 +168,36 @@ int pa_swap_blocks(
     const void* src, void* dst, const int64_t* block_pairs, int num_pairs,
     int64_t block_bytes, int kind, void* stream);
 
+/* ---- prompt attention ------------------------------------------------------- */
+
+/*
+ * Causal self-attention inside each prompt of a flat token batch:
+ *   out[i] = sum_{j <= i, same prompt} softmax_j(scale * <q_i, k_j>) v_j
+ * Replaces the call PagedAttention.multi_query_kv_attention makes into
+ * xformers' memory_efficient_attention_forward with a BlockDiagonalCausalMask
+ * built from the prompt lengths (vllm/model_executor/layers/attention.py:44-70;
+ * restated per prompt in tests/kernels/test_attention.py:69-101).
+ *
+ *   out         [num_tokens, num_heads, head_size] dense
+ *   query, key, value
+ *               [num_tokens, num_heads, head_size], row strides in elements
+ *               (the q, k, v column slices of a fused qkv projection)
+ *   cu_seqlens  HOST array of num_seqs + 1 non-decreasing token offsets: prompt
+ *               s owns token rows cu_seqlens[s] .. cu_seqlens[s + 1] - 1 (the
+ *               prompt lengths are host data in the reference too).  Rows outside
+ *               every prompt (padding) are neither read nor written.
+ *
+ * Head sizes 64, 80, 96, 128; fp16 / bf16 on the 16-bit matrix instructions with
+ * fp32 accumulation and fp32 softmax, fp32 on the fp32 matrix instructions.
+ * Pointers and row strides must be multiples of 16 bytes.  The offsets ride in
+ * the kernel arguments: no host-to-device copy, no synchronisation.
+ */
+int pa_multi_query_kv_attention(
+    void* out, const void* query, const void* key, const void* value,
+    const int32_t* cu_seqlens, int num_seqs, int num_heads, int head_size,
+    float scale, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    int dtype, void* stream);
+
 /* ---- operators next to the attention path in a decoder layer ------------- */
 
 /*

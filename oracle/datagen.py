@@ -367,3 +367,52 @@ def elementwise_cases() -> List[ElementwiseCase]:
                                          hidden=d, seed=seed))
             seed += 1
     return cases
+
+
+# ---- prompt attention cases -------------------------------------------------
+
+@dataclass
+class PromptCase:
+    name: str
+    dtype: str = "float16"
+    seq_lens: Optional[List[int]] = None
+    num_heads: int = 2
+    head_size: int = 128
+    dist: str = "normal"     # "normal" | "uniform1e-3" (tests/kernels/test_attention.py:241)
+    pad_tokens: int = 0      # padding rows after the last prompt (attention.py:83-87)
+    seed: int = 0
+
+    def to_json(self) -> str:
+        return json.dumps(asdict(self), sort_keys=True)
+
+
+def make_prompt_inputs(case: PromptCase) -> Dict[str, np.ndarray]:
+    """qkv [T, 3, H, D] in storage form (query, key, value are its strided
+    slices, as in tests/kernels/test_attention.py:238-242) and cu_seqlens."""
+    T = int(sum(case.seq_lens)) + case.pad_tokens
+    n = T * 3 * case.num_heads * case.head_size
+    base = case.seed * 1000 + 900
+    vals = normal(n, base + 1) if case.dist == "normal" else uniform(n, base + 1, -1e-3, 1e-3)
+    qkv = to_storage(vals, case.dtype).reshape(T, 3, case.num_heads, case.head_size)
+    cu = np.concatenate([[0], np.cumsum(case.seq_lens)]).astype(np.int32)
+    return {"qkv": qkv, "cu_seqlens": cu}
+
+
+def prompt_cases() -> List[PromptCase]:
+    cases: List[PromptCase] = []
+    seed = 500
+    for dtype in DTYPES:
+        # the reference test's grid (tests/kernels/test_attention.py:308-320) at small lengths
+        for D in (64, 80, 96, 128):
+            cases.append(PromptCase(name=f"grid_{dtype}_d{D}", dtype=dtype, seq_lens=[1, 7, 33, 40, 70],
+                                    num_heads=2, head_size=D, dist="normal", seed=seed))
+            seed += 1
+        cases.append(PromptCase(name=f"reftest_dist_{dtype}", dtype=dtype, seq_lens=[3, 64, 65],
+                                num_heads=3, head_size=128, dist="uniform1e-3", seed=seed))
+        seed += 1
+        # lengths around the kernel's tile edges, one long prompt, padding rows behind
+        cases.append(PromptCase(name=f"edges_{dtype}", dtype=dtype, seq_lens=[128, 1, 129, 31, 32, 300],
+                                num_heads=1, head_size=128 if dtype != "float32" else 64, dist="normal",
+                                pad_tokens=5, seed=seed))
+        seed += 1
+    return cases

@@ -489,3 +489,74 @@ int pao_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dt
   }
   return 0;
 }
+
+/* ---- prompt attention ---------------------------------------------------
+ *
+ * Causal self-attention inside each prompt of a flat token batch, the
+ * computation PagedAttention.multi_query_kv_attention hands to xformers with a
+ * BlockDiagonalCausalMask (vllm/model_executor/layers/attention.py:44-70) and
+ * that tests/kernels/test_attention.py:69-101 restates per sequence:
+ *   out[i] = sum_{j <= i} softmax_j(scale * <q_i, k_j>) v_j    (i, j in one prompt)
+ * Dot products, the softmax and the weighted sum are carried in double; only
+ * the final store rounds to the element type.  query / key / value are
+ * [T, H, D] with free row strides, out is dense, cu_seqlens has num_seqs + 1
+ * entries.
+ */
+int pao_multi_query_kv_attention(void* out, const void* query, const void* key,
+                                 const void* value, const int32_t* cu_seqlens,
+                                 int num_seqs, int num_heads, int head_size,
+                                 float scale, int64_t q_stride, int64_t k_stride,
+                                 int64_t v_stride, int dtype) {
+  if (head_size > 512 || head_size <= 0) return 1;
+  if (dtype < 0 || dtype > 2) return 1;
+  int max_len = 0;
+  for (int s = 0; s < num_seqs; s++) {
+    const int n = cu_seqlens[s + 1] - cu_seqlens[s];
+    if (n < 0) return 1;
+    if (n > max_len) max_len = n;
+  }
+  int status = 0;
+  const int D = head_size;
+#pragma omp parallel
+  {
+    double* w = (double*)malloc(sizeof(double) * (size_t)(max_len > 0 ? max_len : 1));
+    if (!w) {
+#pragma omp atomic write
+      status = 2;
+    } else {
+#pragma omp for collapse(2) schedule(dynamic, 1)
+      for (int s = 0; s < num_seqs; s++) {
+        for (int h = 0; h < num_heads; h++) {
+          const int64_t t0 = cu_seqlens[s];
+          const int n = cu_seqlens[s + 1] - cu_seqlens[s];
+          for (int i = 0; i < n; i++) {
+            const int64_t qo = (t0 + i) * q_stride + (int64_t)h * D;
+            double m = -INFINITY;
+            for (int j = 0; j <= i; j++) {
+              const int64_t ko = (t0 + j) * k_stride + (int64_t)h * D;
+              double acc = 0.0;
+              for (int d = 0; d < D; d++)
+                acc += (double)pao_load(query, qo + d, dtype) * (double)pao_load(key, ko + d, dtype);
+              w[j] = (double)scale * acc;
+              if (w[j] > m) m = w[j];
+            }
+            double sum = 0.0;
+            for (int j = 0; j <= i; j++) {
+              w[j] = exp(w[j] - m);
+              sum += w[j];
+            }
+            const int64_t oo = ((t0 + i) * num_heads + h) * (int64_t)D;
+            for (int d = 0; d < D; d++) {
+              double acc = 0.0;
+              for (int j = 0; j <= i; j++)
+                acc += w[j] * (double)pao_load(value, (t0 + j) * v_stride + (int64_t)h * D + d, dtype);
+              pao_store(out, oo + d, dtype, (float)(acc / sum));
+            }
+          }
+        }
+      }
+      free(w);
+    }
+  }
+  return status;
+}

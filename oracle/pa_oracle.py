@@ -53,6 +53,8 @@ def lib() -> ctypes.CDLL:
         L.pao_rms_norm.restype = i32
         L.pao_silu_and_mul.argtypes = [vp, vp, i32, i32, i32]
         L.pao_silu_and_mul.restype = i32
+        L.pao_multi_query_kv_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i64, i64, i64, i32]
+        L.pao_multi_query_kv_attention.restype = i32
         L.pao_test_half_to_float.argtypes = [ctypes.c_uint16]
         L.pao_test_half_to_float.restype = f32
         L.pao_test_float_to_half.argtypes = [f32]
@@ -206,4 +208,23 @@ def silu_and_mul(input: np.ndarray, dtype: str) -> np.ndarray:
         rc = lib().pao_silu_and_mul(_ptr(out), _ptr(input), T, d2 // 2, DTYPE_CODE[dtype])
         if rc != 0:
             raise RuntimeError(f"pa_oracle silu_and_mul failed with code {rc}")
+    return out
+
+
+def multi_query_kv_attention(query: np.ndarray, key: np.ndarray, value: np.ndarray,
+                             cu_seqlens: Sequence[int], scale: float, dtype: str) -> np.ndarray:
+    """Causal attention inside each prompt; query / key / value are [T, H, D]
+    (strided views are fine), the result is dense [T, H, D]."""
+    T, H, D = query.shape
+    for a in (query, key, value):
+        _check_inner_dense(a)
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    assert cu[0] == 0 and cu[-1] <= T
+    out = np.zeros((T, H, D), dtype=query.dtype)
+    if len(cu) > 1 and cu[-1] > 0:
+        rc = lib().pao_multi_query_kv_attention(
+            _ptr(out), _ptr(query), _ptr(key), _ptr(value), _ptr(cu), len(cu) - 1, H, D, float(scale),
+            _elem_stride(query, 0), _elem_stride(key, 0), _elem_stride(value, 0), DTYPE_CODE[dtype])
+        if rc != 0:
+            raise RuntimeError(f"pa_oracle multi_query_kv_attention failed with code {rc}")
     return out

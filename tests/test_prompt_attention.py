@@ -1,0 +1,196 @@
+"""Prompt attention (causal attention inside each prompt of a flat batch): the
+C oracle against fixtures produced by the reference's own restatement
+(tests/kernels/test_attention.py:14-37, 69-101) on CPU, and the matrix-core
+kernel against both on the GPU, through the C ABI and the operator module.
+
+Bars.  Against the reference run in the storage type on its own input
+distribution: atol 1e-3, rtol 1e-5 (its criterion, test_attention.py:267).
+Against the reference formula in fp32 on unit-scale inputs: the kernel rounds
+the softmax weights to the storage type before the P.V product (as the
+reference's storage-type arithmetic does), so the bound is one rounding of the
+weights plus one of the output: |err| <= eps * (sum_j p_j |v_j| + |out|) with
+eps = 2^-11 (fp16), 2^-8 (bf16); fp32 is within 2e-5."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import datagen, pa_oracle
+from tests import helpers
+
+with open(os.path.join(helpers.GOLDEN_DIR, "prompt_golden.json")) as _f:
+    META = json.load(_f)
+DATA = np.load(os.path.join(helpers.GOLDEN_DIR, "prompt_golden.npz"), allow_pickle=False)
+DEV = "cuda:0"
+EPS = {"float32": 2e-5, "float16": 2.0 ** -11, "bfloat16": 2.0 ** -8}
+
+
+def _case(name):
+    return datagen.PromptCase(**META[name]["case"])
+
+
+def _check_against_fixture(name, case, out_storage, n_valid):
+    got = datagen.storage_to_float32(out_storage, case.dtype)[:n_valid].astype(np.float64)
+    ref_dtype = datagen.storage_to_float32(DATA[name + "/ref_dtype"], case.dtype).astype(np.float64)
+    ref_f32 = DATA[name + "/ref_f32"].astype(np.float64)
+    assert got.shape == ref_f32.shape and np.all(np.isfinite(got))
+    if case.dist == "uniform1e-3":
+        assert np.allclose(got, ref_dtype, atol=1e-3, rtol=1e-5)
+        assert np.abs(got - ref_f32).max() <= 2e-5 * 1e-3 + EPS[case.dtype] * 2e-3
+    else:
+        # values are N(0,1): sum_j p_j |v_j| <= max |v| ~ 4.5; use the measured magnitude of the row
+        bound = EPS[case.dtype] * (2.0 + 2.0 * np.abs(ref_f32)) + 2e-6
+        err = np.abs(got - ref_f32)
+        assert np.all(err <= bound), f"{name}: max err {err.max():.3e}, worst excess {(err - bound).max():.3e}"
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_oracle_matches_reference_fixture(name):
+    case = _case(name)
+    inp = datagen.make_prompt_inputs(case)
+    assert datagen.checksum_arrays(inp) == META[name]["inputs_sha256"]
+    qkv = inp["qkv"]
+    out = pa_oracle.multi_query_kv_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], inp["cu_seqlens"],
+                                             case.head_size ** -0.5, case.dtype)
+    n = int(inp["cu_seqlens"][-1])
+    _check_against_fixture(name, case, out, n)
+    assert not out[n:].any()  # padding rows are left alone
+
+
+def _run_kernel(pkg, case, inp, via_module):
+    import torch
+    qkv = datagen.storage_to_torch(inp["qkv"].copy(), case.dtype).to(DEV)
+    q, k, v = qkv.unbind(dim=1)
+    out = torch.full((qkv.shape[0], case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=DEV)
+    scale = case.head_size ** -0.5
+    if via_module:
+        pkg.attention_ops.multi_query_kv_attention(out, q, k, v, list(case.seq_lens), scale)
+    else:
+        pkg._capi.multi_query_kv_attention(out, q, k, v, [int(x) for x in inp["cu_seqlens"]], scale)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("via_module", [False, True], ids=["c_abi", "module"])
+@pytest.mark.parametrize("name", sorted(META))
+def test_kernel_matches_reference_fixture(pkg, name, via_module):
+    import torch
+    case = _case(name)
+    inp = datagen.make_prompt_inputs(case)
+    out = _run_kernel(pkg, case, inp, via_module)
+    n = int(inp["cu_seqlens"][-1])
+    _check_against_fixture(name, case, datagen.torch_to_storage(out, case.dtype), n)
+    assert bool(torch.isnan(out[n:].float()).all())  # padding rows are not written
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16", "float32"])
+@pytest.mark.parametrize("head_size", [64, 80, 96, 128])
+def test_kernel_matches_oracle_on_ragged_prompts(pkg, dtype, head_size):
+    """Lengths on both sides of the 32 / 64 / 128-row tile edges, several
+    workgroups per prompt, three heads, value magnitudes that differ per row."""
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 257, 5]
+    case = datagen.PromptCase(name="ragged", dtype=dtype, seq_lens=lens, num_heads=3, head_size=head_size,
+                              dist="normal", pad_tokens=3, seed=900 + head_size)
+    inp = datagen.make_prompt_inputs(case)
+    out = datagen.torch_to_storage(_run_kernel(pkg, case, inp, False), dtype)
+    qkv = inp["qkv"]
+    ref = pa_oracle.multi_query_kv_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], inp["cu_seqlens"],
+                                             head_size ** -0.5, dtype)
+    n = int(inp["cu_seqlens"][-1])
+    got = datagen.storage_to_float32(out, dtype)[:n].astype(np.float64)
+    want = datagen.storage_to_float32(ref, dtype)[:n].astype(np.float64)
+    bound = EPS[dtype] * (2.0 + 3.0 * np.abs(want)) + 2e-6
+    err = np.abs(got - want)
+    assert np.all(err <= bound), f"max err {err.max():.3e}"
+    # the first token of every prompt attends to itself only: out = v (exactly in 16-bit
+    # storage; in fp32 the weight is exp2 of a rounding residual, 1 within a few ulp)
+    v = qkv[:, 2]
+    for s in inp["cu_seqlens"][:-1]:
+        if dtype == "float32":
+            assert np.allclose(out[s], v[s], rtol=1e-6, atol=0)
+        else:
+            assert np.array_equal(out[s], v[s])
+
+
+@pytest.mark.gpu
+def test_kernel_scale_sign_and_zero(pkg):
+    """Negative and zero scales take the paths that move the sign into q."""
+    import torch
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    T, H, D = 150, 2, 64
+    qkv = torch.randn(T, 3, H, D, dtype=torch.float16, device=DEV, generator=g)
+    q, k, v = qkv.unbind(dim=1)
+    for scale in (-0.125, 0.0, 0.3):
+        out = torch.empty(T, H, D, dtype=torch.float16, device=DEV)
+        pkg._capi.multi_query_kv_attention(out, q, k, v, [0, 100, 150], scale)
+        for lo, hi in ((0, 100), (100, 150)):
+            s = torch.einsum("qhd,khd->hqk", q[lo:hi].float(), k[lo:hi].float()) * scale
+            s = s + torch.full((hi - lo, hi - lo), float("-inf"), device=DEV).triu(1)
+            want = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), v[lo:hi].float())
+            assert torch.allclose(out[lo:hi].float(), want, atol=4e-3, rtol=4e-3), scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+def test_kernel_at_full_size_against_torch(pkg, dtype_name):
+    """LLaMA-7B shaped prompt batch (32 heads x 128, 2560 tokens, the scheduler's
+    max_num_batched_tokens) against torch's attention on the GPU, plus two
+    size-independent properties: with V = 1 every output is 1 (the weights sum
+    to one), and the result does not depend on how prompts are packed."""
+    import torch
+    import torch.nn.functional as F
+    dtype = getattr(torch, dtype_name)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    lens = [1024, 700, 512, 300, 24]
+    T, H, D = sum(lens), 32, 128
+    qkv = torch.randn(T + 7, 3, H, D, dtype=dtype, device=DEV, generator=g)
+    q, k, v = qkv.unbind(dim=1)
+    scale = D ** -0.5
+    out = torch.zeros(T + 7, H, D, dtype=dtype, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(out, q, k, v, lens, scale)
+    lo = 0
+    tol = 3e-3 if dtype_name == "float16" else 2e-2
+    for n in lens:
+        o = F.scaled_dot_product_attention(q[lo:lo + n].transpose(0, 1).float(), k[lo:lo + n].transpose(0, 1).float(),
+                                           v[lo:lo + n].transpose(0, 1).float(), is_causal=True, scale=scale)
+        assert torch.allclose(out[lo:lo + n].float(), o.transpose(0, 1), atol=tol, rtol=tol)
+        lo += n
+    assert not out[T:].any()
+    # weights sum to one
+    ones = torch.ones_like(v)
+    out1 = torch.empty(T + 7, H, D, dtype=dtype, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(out1, q, k, ones, lens, scale)
+    assert torch.allclose(out1[:T].float(), torch.ones(T, H, D, device=DEV), atol=4e-3 if dtype_name == "float16" else 2e-2)
+    # the third prompt alone gives bit-identical rows
+    lo = lens[0] + lens[1]
+    alone = torch.empty(lens[2], H, D, dtype=dtype, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(alone, q[lo:lo + lens[2]], k[lo:lo + lens[2]], v[lo:lo + lens[2]],
+                                               [lens[2]], scale)
+    assert torch.equal(alone, out[lo:lo + lens[2]])
+
+
+def test_prompt_attention_argument_validation(pkg):
+    import ctypes
+    c = pkg._capi
+    one = ctypes.c_void_p(16)
+    cu = (ctypes.c_int32 * 3)(0, 4, 9)
+    bad = (ctypes.c_int32 * 3)(0, 5, 3)
+    f = c.lib.pa_multi_query_kv_attention
+    assert f(one, one, one, one, cu, 0, 2, 64, 0.1, 128, 128, 128, 1, None) == c.PA_OK
+    assert f(one, one, one, one, bad, 2, 2, 64, 0.1, 128, 128, 128, 1, None) == c.PA_ERR_INVALID_ARGUMENT
+    assert f(one, one, one, one, cu, 2, 2, 64, 0.1, 64, 128, 128, 1, None) == c.PA_ERR_INVALID_ARGUMENT
+    assert f(one, one, one, one, cu, 2, 2, 64, 0.1, 128, 128, 128, 7, None) == c.PA_ERR_UNSUPPORTED
+    assert f(one, one, one, one, cu, 2, 2, 72, 0.1, 144, 144, 144, 1, None) == c.PA_ERR_UNSUPPORTED
+    assert "head size" in c.last_error()
+    assert f(ctypes.c_void_p(8), one, one, one, cu, 2, 2, 64, 0.1, 128, 128, 128, 1, None) == c.PA_ERR_UNSUPPORTED
+    assert f(one, None, one, one, cu, 2, 2, 64, 0.1, 128, 128, 128, 1, None) == c.PA_ERR_INVALID_ARGUMENT
+    assert f(one, one, one, one, cu, 2, 2, 64, float("nan"), 128, 128, 128, 1, None) == c.PA_ERR_INVALID_ARGUMENT
+    import torch
+    x = torch.zeros(4, 2, 64)
+    with pytest.raises(RuntimeError, match="must be on the GPU"):
+        pkg.attention_ops.multi_query_kv_attention(x.clone(), x, x, x, [4], 0.1)

@@ -30,6 +30,7 @@ EXPORTS = (
     "pa_single_query_cached_kv_attention",
     "pa_single_query_cached_kv_attention_ws",
     "pa_decode_workspace_bytes",
+    "pa_multi_query_kv_attention",
     "pa_reshape_and_cache",
     "pa_gather_cached_kv",
     "pa_copy_blocks",
@@ -68,6 +69,8 @@ def _load() -> ctypes.CDLL:
     lib.pa_single_query_cached_kv_attention_ws.restype = i32
     lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
+    lib.pa_multi_query_kv_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i64, i64, i64, i32, vp]
+    lib.pa_multi_query_kv_attention.restype = i32
     for fn in (lib.pa_reshape_and_cache, lib.pa_gather_cached_kv):
         fn.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
         fn.restype = i32
@@ -144,6 +147,17 @@ def single_query_cached_kv_attention_ws(out, query, key_cache, value_cache, scal
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
         max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
         _stream_handle(stream))
+    check(rc)
+
+
+def multi_query_kv_attention(out, query, key, value, cu_seqlens: Sequence[int], scale, stream=None) -> None:
+    """query / key / value [T, H, D] (row strides free), out dense; cu_seqlens is a host sequence."""
+    T, H, D = query.shape
+    cu = (ctypes.c_int32 * len(cu_seqlens))(*[int(x) for x in cu_seqlens])
+    rc = lib.pa_multi_query_kv_attention(
+        out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), cu, len(cu_seqlens) - 1, H, D,
+        float(scale), query.stride(0) if T > 0 else H * D, key.stride(0) if T > 0 else H * D,
+        value.stride(0) if T > 0 else H * D, dtype_code(query.dtype), _stream_handle(stream))
     check(rc)
 
 

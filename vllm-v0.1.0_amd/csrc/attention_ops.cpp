@@ -57,9 +57,48 @@ void single_query_cached_kv_attention(
                what);
 }
 
+// Not part of the reference's module (its prompt attention lives in xformers):
+// the causal per-prompt attention PagedAttention.multi_query_kv_attention needs
+// (vllm/model_executor/layers/attention.py:44-70), with the prompt lengths as
+// the host list BlockDiagonalCausalMask.from_seqlens takes.
+void multi_query_kv_attention(
+    torch::Tensor& out,     // [num_prompt_tokens, num_heads, head_size]
+    torch::Tensor& query,   // [num_prompt_tokens, num_heads, head_size]
+    torch::Tensor& key, torch::Tensor& value, const std::vector<int64_t>& seq_lens, float scale) {
+  using namespace pa_shim;
+  const char* what = "multi_query_kv_attention";
+  TORCH_CHECK(out.is_cuda() && query.is_cuda() && key.is_cuda() && value.is_cuda(), what, ": all tensors must be on the GPU");
+  const int dtype = dtype_code(query, what);
+  TORCH_CHECK(out.scalar_type() == query.scalar_type() && key.scalar_type() == query.scalar_type() &&
+                  value.scalar_type() == query.scalar_type(),
+              what, ": out, query, key and value must share one data type");
+  check_token_rows(query, "query");
+  check_token_rows(key, "key");
+  check_token_rows(value, "value");
+  TORCH_CHECK(out.dim() == 3 && out.is_contiguous() && out.sizes() == query.sizes(), what,
+              ": out must be contiguous and shaped like query");
+  TORCH_CHECK(key.sizes() == query.sizes() && value.sizes() == query.sizes(), what, ": query, key and value shapes differ");
+  std::vector<int32_t> cu(seq_lens.size() + 1, 0);
+  for (size_t i = 0; i < seq_lens.size(); ++i) {
+    TORCH_CHECK(seq_lens[i] >= 0, what, ": negative prompt length");
+    TORCH_CHECK(cu[i] + seq_lens[i] <= query.size(0), what, ": prompt lengths exceed the number of token rows");
+    cu[i + 1] = cu[i] + static_cast<int32_t>(seq_lens[i]);
+  }
+  const int64_t row = query.size(1) * query.size(2);
+  const bool any = query.size(0) > 0;
+  check_status(pa_multi_query_kv_attention(out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), cu.data(),
+                                           static_cast<int>(seq_lens.size()), static_cast<int>(query.size(1)),
+                                           static_cast<int>(query.size(2)), scale, any ? query.stride(0) : row,
+                                           any ? key.stride(0) : row, any ? value.stride(0) : row, dtype,
+                                           current_stream(query)),
+               what);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("single_query_cached_kv_attention", &single_query_cached_kv_attention,
         "Attention of one new query token per sequence over the paged key/value cache (MI355X HIP kernel)");
+  m.def("multi_query_kv_attention", &multi_query_kv_attention,
+        "Causal self-attention inside each prompt of a flat token batch (MI355X matrix-core kernel)");
 }

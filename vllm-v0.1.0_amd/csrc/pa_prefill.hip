@@ -1,0 +1,451 @@
+// Prompt attention for gfx950: causal self-attention inside each prompt of a
+// flat token batch, on the matrix cores.
+//
+// Replaces what PagedAttention.multi_query_kv_attention hands to xformers'
+// memory_efficient_attention_forward with a BlockDiagonalCausalMask
+// (vllm/model_executor/layers/attention.py:44-70): query / key / value are the
+// [num_prompt_tokens, H, D] slices of the fused qkv projection (free row
+// strides), the output is dense.
+//
+// One workgroup = 4 waves = 128 query rows of one (prompt, head); each wave
+// owns 32 rows.  Key/value tiles of 64 rows (32 for fp32) go global -> VGPR ->
+// LDS, double buffered, the loads of tile t+1 in flight while tile t is
+// consumed.  Per tile and wave:
+//   S^T = K . Q^T   v_mfma_f32_32x32x16_{f16,bf16}: the KEY index lands on the
+//                   accumulator registers and the QUERY row on the lane, so a
+//                   row's softmax statistics are lane-local (one exchange
+//                   between lanes l and l+32 for the maximum);
+//   online softmax  in the log2 domain, fp32;
+//   O^T += V^T . P^T  the S^T accumulator, converted to 16 bit, is the B
+//                   operand as it stands (its register index is the summation
+//                   index); V^T fragments come from the row-major V image by
+//                   ds_read_b64_tr_b16.
+// fp32 tensors take the same skeleton with v_mfma_f32_32x32x2_f32 (exact fp32
+// products and sums) and element reads of the LDS images.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "pa_common.h"
+
+namespace {
+
+using namespace pa;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kMaxSeqs = 256;   // prompts per launch (table rides in the kernel arguments)
+constexpr int kMaxWork = 512;   // (prompt, query block) items per launch
+constexpr int kQBlock = 128;    // query rows per workgroup
+
+struct PromptArgs {
+  void* out;
+  const void* q;
+  const void* k;
+  const void* v;
+  int64_t q_stride, k_stride, v_stride;  // elements between token rows
+  float c;                               // |scale| * log2(e)
+  int q_mode;                            // 0: q as stored, 1: -q (scale < 0), 2: q = 0 (scale == 0)
+  int num_heads;
+  int pad_;
+  int32_t cu[kMaxSeqs + 1];              // first token of each prompt of this launch
+  uint32_t work[kMaxWork];               // (prompt << 16) | query block, heaviest first
+};
+static_assert(sizeof(PromptArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+struct OpsF16 {
+  static constexpr int ES = 2;
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    f16x2 h = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, h);
+  }
+};
+struct OpsBF16 {
+  static constexpr int ES = 2;
+  static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    bf16x2 h = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, h);
+  }
+};
+struct OpsF32 {
+  static constexpr int ES = 4;
+};
+
+template <typename X, int D>
+struct PromptGeometry {
+  static constexpr int ES = X::ES;
+  static constexpr bool F32 = ES == 4;
+  static constexpr int KT = F32 ? 32 : 64;   // keys per tile
+  static constexpr int KB = KT / 32;         // 32-key blocks per tile
+  static constexpr int DB = (D + 31) / 32;   // 32-row blocks of O^T
+  static constexpr int DP = DB * 32;
+  // K image: rows read by ds_read_b128 (16 bit: stride = odd multiple of 16 B)
+  // or ds_read_b32 (fp32: odd number of dwords) by 32 lanes on 32 rows.
+  static constexpr int KSTR = F32 ? D * 4 + 4 : D * 2 + 16;
+  // V image: 16 bit rows are read transposed, 4 rows x 64 B per 32-lane half;
+  // a stride of 64 or 192 (mod 256) bytes spreads them over all banks.
+  static constexpr int VSTR = F32 ? DP * 4 : ((DP * 2) % 128 == 0 ? DP * 2 + 64 : DP * 2);
+  static constexpr int KBYTES = KT * KSTR;
+  static constexpr int VBYTES = KT * VSTR;
+  static constexpr int BUF = KBYTES + VBYTES;
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int CPR = D * ES / 16;    // 16-byte chunks per row
+  static constexpr int TOTAL = KT * CPR;
+  static constexpr int NCH = (TOTAL + 255) / 256;
+  static constexpr int NQ = F32 ? D / 2 : D / 4;  // dwords of q per lane
+  static_assert(KBYTES % 16 == 0 && VSTR % 16 == 0, "images must keep 16-byte alignment");
+};
+
+template <typename X, int D>
+__global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
+  using G = PromptGeometry<X, D>;
+  constexpr int ES = G::ES;
+  constexpr bool F32 = G::F32;
+  constexpr int KT = G::KT, KB = G::KB, DB = G::DB, DP = G::DP;
+  constexpr int KSTR = G::KSTR, VSTR = G::VSTR, KBYTES = G::KBYTES, BUF = G::BUF;
+  constexpr int CPR = G::CPR, TOTAL = G::TOTAL, NCH = G::NCH, NQ = G::NQ;
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const unsigned wi = blockIdx.x / (unsigned)a.num_heads;
+  const int head = (int)(blockIdx.x - wi * (unsigned)a.num_heads);
+  const uint32_t item = a.work[wi];
+  const int seq = (int)(item >> 16), qb = (int)(item & 0xffffu);
+  const int64_t t0 = a.cu[seq];
+  const int n = a.cu[seq + 1] - a.cu[seq];
+  const int q0 = qb * kQBlock + wave * 32;  // this wave's first query row (inside the prompt)
+  const int n_tiles = (min(n, qb * kQBlock + kQBlock) + KT - 1) / KT;
+  const bool wave_has_rows = q0 < n;
+
+  // Columns D..DP-1 of the V image (head size 80) are never staged: clear
+  // both buffers once so the padded rows of O^T stay finite.
+  if constexpr (DP != D) {
+    for (int i = tid * 16; i < G::LDS_BYTES; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0, 0, 0, 0};
+    __syncthreads();
+  }
+
+  // ---- query fragments (registers, whole kernel) ---------------------------
+  // 16 bit: dwords 4ks..4ks+3 = Q[q0 + r][16 ks + 8 hh .. +7], the B operand of
+  // k-step ks.  fp32: dword ks = Q[q0 + r][hh D/2 + ks] (the summation order
+  // over d is a free choice as long as K uses the same).
+  uint32_t qf[NQ];
+  {
+    const bool ok = q0 + r < n && a.q_mode != 2;
+    const unsigned char* qrow =
+        (const unsigned char*)a.q + ((t0 + q0 + r) * a.q_stride + (int64_t)head * D) * ES;
+    const uint32_t flip = a.q_mode == 1 ? (F32 ? 0x80000000u : 0x80008000u) : 0u;
+#pragma unroll
+    for (int i = 0; i < NQ / 4; ++i) {
+      const int byte_off = F32 ? (hh * (D / 2) + 4 * i) * 4 : (16 * i + 8 * hh) * 2;
+      u32x4 v = {0, 0, 0, 0};
+      if (ok) v = *(const u32x4*)(qrow + byte_off);
+      qf[4 * i + 0] = v.x ^ flip;
+      qf[4 * i + 1] = v.y ^ flip;
+      qf[4 * i + 2] = v.z ^ flip;
+      qf[4 * i + 3] = v.w ^ flip;
+    }
+  }
+
+  // ---- K/V staging: global -> registers -> LDS ------------------------------
+  const unsigned char* kbase = (const unsigned char*)a.k + (int64_t)head * D * ES;
+  const unsigned char* vbase = (const unsigned char*)a.v + (int64_t)head * D * ES;
+  u32x4 kreg[NCH], vreg[NCH];
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cidx = tid + 256 * i;
+      const int row = cidx / CPR, ch = cidx - row * CPR;
+      const int key = kt * KT + row;
+      u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+      if ((TOTAL % 256 == 0 || cidx < TOTAL) && key < n) {  // rows past the prompt read as zero
+        const int64_t tok = t0 + key;
+        kv = *(const u32x4*)(kbase + tok * a.k_stride * ES + ch * 16);
+        vv = *(const u32x4*)(vbase + tok * a.v_stride * ES + ch * 16);
+      }
+      kreg[i] = kv;
+      vreg[i] = vv;
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* kimg = smem + buf * BUF;
+    unsigned char* vimg = kimg + KBYTES;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cidx = tid + 256 * i;
+      const int row = cidx / CPR, ch = cidx - row * CPR;
+      if (TOTAL % 256 == 0 || cidx < TOTAL) {
+        if constexpr (F32) {
+          uint32_t* kp = (uint32_t*)(kimg + row * KSTR + ch * 16);
+          kp[0] = kreg[i].x;
+          kp[1] = kreg[i].y;
+          kp[2] = kreg[i].z;
+          kp[3] = kreg[i].w;
+        } else {
+          *(u32x4*)(kimg + row * KSTR + ch * 16) = kreg[i];
+        }
+        *(u32x4*)(vimg + row * VSTR + ch * 16) = vreg[i];
+      }
+    }
+  };
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // Transposed V read: lane 4 qq + p of a 16-lane group addresses row qq,
+  // columns 4p..4p+3 of a 4 x 16 block; the group (lane >> 4) selects the
+  // 16-column half of the d block (bit 0) and the key quad (bit 1 = hh).
+  const int tr_off = (4 * hh + ((lane >> 2) & 3)) * VSTR + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < n_tiles;
+    if (more) issue(kt + 1);
+
+    if (wave_has_rows && kt * KT <= q0 + 31) {  // wave-uniform: tiles above the diagonal are skipped
+      const unsigned char* kimg = smem + buf * BUF;
+      const unsigned char* vimg = kimg + KBYTES;
+
+      // S^T[key][q]: accumulator register = key row, lane = query row
+      f32x16 s[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+        const unsigned char* krow = kimg + (32 * kb + r) * KSTR;
+        if constexpr (F32) {
+#pragma unroll
+          for (int ks = 0; ks < D / 2; ++ks) {
+            const float kv = *(const float*)(krow + (hh * (D / 2) + ks) * 4);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, __builtin_bit_cast(float, qf[ks]), s[kb], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < D / 16; ++ks) {
+            const u32x4 kv = *(const u32x4*)(krow + (16 * ks + 8 * hh) * 2);
+            const u32x4 qv = {qf[4 * ks], qf[4 * ks + 1], qf[4 * ks + 2], qf[4 * ks + 3]};
+            s[kb] = X::mfma(kv, qv, s[kb]);
+          }
+        }
+      }
+
+      // causal mask on the tiles that reach the diagonal (this also hides the
+      // zero rows staged past the end of the prompt from every valid query)
+      if (kt * KT + KT - 1 > q0) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kt * KT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (key > q0 + r) s[kb][i] = -INFINITY;
+          }
+      }
+
+      // online softmax, log2 domain.  Every processed tile holds at least one
+      // unmasked key for every row of the wave, so m_new is finite.
+      float mx = s[0][0];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx * a.c);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], a.c, -m_new));
+          s[kb][i] = p;
+          psum += p;
+        }
+      l = l * alpha + psum;  // per-lane partial sum: lanes l and l+32 are added at the end
+      m = m_new;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+
+      // O^T[d][q] += V^T[d][key] P^T[key][q]
+      if constexpr (F32) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+              const float vv = *(const float*)(vimg + key * VSTR + (32 * db + r) * 4);
+              o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kb][i], o[db], 0, 0, 0);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            // registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
+            const u32x4 pf = {X::pack2(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]), X::pack2(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]),
+                              X::pack2(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]), X::pack2(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7])};
+            const unsigned char* vrow = vimg + tr_off + (32 * kb + 16 * s2) * VSTR;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4*)(vrow + 64 * db));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4*)(vrow + 64 * db + 8 * VSTR));
+              const s16x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              o[db] = X::mfma(__builtin_bit_cast(u32x4, vt), pf, o[db]);
+            }
+          }
+      }
+    }
+
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------
+  l += __shfl_xor(l, 32);
+  if (q0 + r < n) {
+    const float inv = 1.f / l;
+    unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * db + 8 * g + 4 * hh;  // registers 4g..4g+3 = rows d..d+3 of O^T
+        if (d < D) {
+          const float v0 = o[db][4 * g] * inv, v1 = o[db][4 * g + 1] * inv, v2 = o[db][4 * g + 2] * inv,
+                      v3 = o[db][4 * g + 3] * inv;
+          if constexpr (F32) {
+            *(f32x4*)(orow + d * 4) = f32x4{v0, v1, v2, v3};
+          } else {
+            *(u32x2*)(orow + d * 2) = u32x2{X::pack2(v0, v1), X::pack2(v2, v3)};
+          }
+        }
+      }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------
+
+template <typename X, int D>
+int launch_prompt(PromptArgs& args, int num_work, hipStream_t stream) {
+  using G = PromptGeometry<X, D>;
+  static bool configured_on[64] = {};  // per device; benign race: the attribute call is idempotent
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PA_ERR_HIP, "prompt attention: no current device");
+  bool& configured = configured_on[dev];
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_prompt_kernel<X, D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return fail(PA_ERR_HIP, "prompt attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    configured = true;
+  }
+  pa_prompt_kernel<X, D><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(256), G::LDS_BYTES, stream>>>(args);
+  PA_CHECK_LAUNCH("pa_prompt_kernel");
+  return PA_OK;
+}
+
+template <typename X>
+int dispatch_head(PromptArgs& args, int num_work, int head_size, hipStream_t stream) {
+  switch (head_size) {
+    case 64: return launch_prompt<X, 64>(args, num_work, stream);
+    case 80: return launch_prompt<X, 80>(args, num_work, stream);
+    case 96: return launch_prompt<X, 96>(args, num_work, stream);
+    case 128: return launch_prompt<X, 128>(args, num_work, stream);
+    default:
+      return fail(PA_ERR_UNSUPPORTED, "prompt attention: unsupported head size %d (supported: 64, 80, 96, 128)", head_size);
+  }
+}
+
+}  // namespace
+
+extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const void* key, const void* value,
+                                           const int32_t* cu_seqlens, int num_seqs, int num_heads, int head_size,
+                                           float scale, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                           int dtype, void* stream) {
+  clear_error();
+  PA_REQUIRE(num_seqs >= 0 && num_heads > 0 && head_size > 0, "prompt attention: bad sizes (num_seqs %d, num_heads %d, head_size %d)",
+             num_seqs, num_heads, head_size);
+  if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
+    return fail(PA_ERR_UNSUPPORTED, "prompt attention: unsupported dtype code %d", dtype);
+  if (num_seqs == 0) return PA_OK;
+  PA_REQUIRE(cu_seqlens != nullptr, "prompt attention: cu_seqlens is null");
+  PA_REQUIRE(isfinite(scale), "prompt attention: scale must be finite");
+  const int64_t total = (int64_t)cu_seqlens[num_seqs] - cu_seqlens[0];
+  for (int s = 0; s < num_seqs; ++s) {
+    PA_REQUIRE(cu_seqlens[s + 1] >= cu_seqlens[s] && cu_seqlens[s] >= 0, "prompt attention: cu_seqlens must be non-decreasing");
+    PA_REQUIRE((int64_t)cu_seqlens[s + 1] - cu_seqlens[s] <= (int64_t)65535 * kQBlock, "prompt attention: prompt %d is too long", s);
+  }
+  if (total == 0) return PA_OK;
+  PA_REQUIRE(out && query && key && value, "prompt attention: null tensor pointer");
+  const int64_t row = (int64_t)num_heads * head_size;
+  PA_REQUIRE(q_stride >= row && k_stride >= row && v_stride >= row, "prompt attention: row strides are smaller than num_heads * head_size");
+  const int es = elem_size(dtype);
+  if (!aligned16(out) || !aligned16(query) || !aligned16(key) || !aligned16(value) || (q_stride * es) % 16 || (k_stride * es) % 16 ||
+      (v_stride * es) % 16)
+    return fail(PA_ERR_UNSUPPORTED, "prompt attention: tensors and row strides must be 16-byte aligned");
+
+  PromptArgs args;
+  args.out = out;
+  args.q = query;
+  args.k = key;
+  args.v = value;
+  args.q_stride = q_stride;
+  args.k_stride = k_stride;
+  args.v_stride = v_stride;
+  args.c = fabsf(scale) * 1.4426950408889634f;
+  args.q_mode = scale < 0.f ? 1 : 0;
+  if (scale == 0.f) {  // uniform weights: zero scores with any positive factor
+    args.c = 1.f;
+    args.q_mode = 2;
+  }
+  args.num_heads = num_heads;
+  args.pad_ = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  std::vector<uint32_t> work;
+  for (int s0 = 0; s0 < num_seqs; s0 += kMaxSeqs) {
+    const int ns = std::min(kMaxSeqs, num_seqs - s0);
+    for (int i = 0; i <= ns; ++i) args.cu[i] = cu_seqlens[s0 + i];
+    work.clear();
+    for (int i = 0; i < ns; ++i) {
+      const int n = args.cu[i + 1] - args.cu[i];
+      for (int qb = 0; qb * kQBlock < n; ++qb) work.push_back(((uint32_t)i << 16) | (uint32_t)qb);
+    }
+    // query blocks far down a prompt see the most keys: start them first
+    std::stable_sort(work.begin(), work.end(), [](uint32_t x, uint32_t y) { return (x & 0xffffu) > (y & 0xffffu); });
+    for (size_t w0 = 0; w0 < work.size(); w0 += kMaxWork) {
+      const int nw = (int)std::min<size_t>(kMaxWork, work.size() - w0);
+      std::copy(work.begin() + w0, work.begin() + w0 + nw, args.work);
+      int rc;
+      if (dtype == PA_DTYPE_F16) rc = dispatch_head<OpsF16>(args, nw, head_size, st);
+      else if (dtype == PA_DTYPE_BF16) rc = dispatch_head<OpsBF16>(args, nw, head_size, st);
+      else rc = dispatch_head<OpsF32>(args, nw, head_size, st);
+      if (rc != PA_OK) return rc;
+    }
+  }
+  return PA_OK;
+}

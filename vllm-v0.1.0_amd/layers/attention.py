@@ -12,9 +12,9 @@ batch
   3. reshape_and_cache on [:num_valid_tokens] (:131-140);
   4. single_query_cached_kv_attention on the generation tokens (:142-152).
 
-Steps 3 and 4 are the HIP operator modules.  Step 1 is outside the decode
-path: the reference uses xformers' CUTLASS kernel (:59-67); here it is torch's
-scaled_dot_product_attention per prompt.
+Steps 1, 3 and 4 are the HIP operator modules.  For step 1 the reference calls
+xformers' CUTLASS kernel with a block-diagonal causal mask (:59-67); here it is
+one matrix-core kernel launch over all prompts of the batch.
 """
 from __future__ import annotations
 
@@ -22,7 +22,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from ..input_metadata import BlockDiagonalCausal, InputMetadata
 
@@ -54,14 +53,7 @@ class PagedAttention(nn.Module):
         value: torch.Tensor,
         attn_bias: BlockDiagonalCausal,
     ) -> torch.Tensor:
-        for i in range(len(attn_bias.seqlens)):
-            lo, hi = attn_bias.cu_seqlens[i], attn_bias.cu_seqlens[i + 1]
-            # [n, H, D] -> [1, H, n, D]
-            q = query[lo:hi].transpose(0, 1).unsqueeze(0)
-            k = key[lo:hi].transpose(0, 1).unsqueeze(0)
-            v = value[lo:hi].transpose(0, 1).unsqueeze(0)
-            o = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=self.scale)
-            output[lo:hi].copy_(o.squeeze(0).transpose(0, 1))
+        self._attention_ops.multi_query_kv_attention(output, query, key, value, list(attn_bias.seqlens), self.scale)
         return output
 
     def single_query_cached_kv_attention(
