@@ -194,3 +194,52 @@ def test_prompt_attention_argument_validation(pkg):
     x = torch.zeros(4, 2, 64)
     with pytest.raises(RuntimeError, match="must be on the GPU"):
         pkg.attention_ops.multi_query_kv_attention(x.clone(), x, x, x, [4], 0.1)
+
+
+COMPAT = os.path.join(os.path.dirname(helpers.GOLDEN_DIR), os.pardir, "vllm-v0.1.0_amd", "compat")
+
+
+def _import_shim(pkg):
+    import importlib
+    import sys
+    path = os.path.abspath(COMPAT)
+    if path not in sys.path:
+        sys.path.insert(0, path)
+    return importlib.import_module("xformers.ops"), importlib.import_module("xformers.ops.fmha.attn_bias")
+
+
+def test_xformers_import_shim_surface(pkg):
+    xops, attn_bias = _import_shim(pkg)
+    mask = attn_bias.BlockDiagonalCausalMask.from_seqlens([3, 5])
+    assert isinstance(mask, xops.AttentionBias) and mask.seqlens == (3, 5)
+    assert xops.fmha.cutlass.FwOp() is not None
+    import torch
+    x = torch.zeros(1, 8, 2, 64)
+    with pytest.raises(NotImplementedError):
+        xops.memory_efficient_attention_forward(x, x, x, attn_bias=None)
+    with pytest.raises(NotImplementedError):
+        xops.memory_efficient_attention_forward(x, x, x, attn_bias=mask, p=0.1)
+
+
+@pytest.mark.gpu
+def test_reference_call_sequence_through_the_import_shim(pkg):
+    """The statements of PagedAttention.multi_query_kv_attention
+    (vllm/model_executor/layers/attention.py:44, 59-69) and of the reference
+    test (tests/kernels/test_attention.py:244-256), run against the shim."""
+    import torch
+    xops, attn_bias_mod = _import_shim(pkg)
+    seq_lens = [9, 130, 77]
+    T, H, D = sum(seq_lens), 3, 96
+    qkv = torch.empty(T, 3, H, D, dtype=torch.half, device=DEV).uniform_(-1e-3, 1e-3)
+    query, key, value = qkv.unbind(dim=1)
+    scale = float(1.0 / (D ** 0.5))
+    attn_op = xops.fmha.cutlass.FwOp()
+    attn_bias = attn_bias_mod.BlockDiagonalCausalMask.from_seqlens(seq_lens)
+    out = xops.memory_efficient_attention_forward(query.unsqueeze(0), key.unsqueeze(0), value.unsqueeze(0),
+                                                  attn_bias=attn_bias, p=0.0, scale=scale, op=attn_op)
+    output = torch.empty(T, H, D, dtype=torch.half, device=DEV)
+    output.copy_(out.squeeze(0))
+    ref = pa_oracle.multi_query_kv_attention(*(datagen.torch_to_storage(t, "float16") for t in (query, key, value)),
+                                             np.concatenate([[0], np.cumsum(seq_lens)]), scale, "float16")
+    got = datagen.torch_to_storage(output, "float16").astype(np.float32)
+    assert np.allclose(got, ref.astype(np.float32), atol=1e-3, rtol=1e-5)
