@@ -251,3 +251,91 @@ def test_reshape_gather_round_trip_at_decode_step_size(pkg):
     assert torch.equal(kc.double().sum(), qkv[:, 1].double().sum())
     assert torch.equal(vc.double().sum(), qkv[:, 2].double().sum())
     assert int(torch.count_nonzero(kc)) <= T * H * D and int(torch.count_nonzero(vc)) <= T * H * D
+
+
+def _prompt_like_slots(rng, lens, B, NB, T_pad):
+    """Consecutive slots per prompt through a scattered block table, padding rows = -1."""
+    blocks = rng.permutation(NB)
+    slots, nxt = [], 0
+    for n in lens:
+        nb = (n + B - 1) // B
+        table = blocks[nxt:nxt + nb]
+        nxt += nb
+        slots += [int(table[i // B]) * B + i % B for i in range(n)]
+    slots += [-1] * (T_pad - len(slots))
+    return np.asarray(slots, dtype=np.int32)
+
+
+@pytest.mark.parametrize("dtype,H,D,B", [("float16", 4, 128, 16), ("bfloat16", 3, 80, 32), ("float32", 2, 64, 8),
+                                         ("float16", 5, 96, 8), ("float32", 3, 128, 16)])
+@pytest.mark.parametrize("pattern", ["prompts", "singles", "mixed"])
+def test_reshape_and_cache_prompt_sized_batches_match_oracle(pkg, dtype, H, D, B, pattern):
+    """Batches large enough for the run-aware kernel: prompt lengths that leave
+    runs unaligned to both the 16-token chunks and the blocks, isolated tokens,
+    and a mix with skipped (negative) slots.  Bit-exact against the oracle on the
+    whole caches (untouched slots keep their previous contents)."""
+    import torch
+    rng = np.random.default_rng(hash((dtype, H, D, B, pattern)) % (2 ** 32))
+    NB = 160
+    if pattern == "prompts":
+        lens = [5, 17, 33, 64, 1, 130, 255, 16, 47, 71]
+        T = sum(lens) + 9
+        slots = _prompt_like_slots(rng, lens, B, NB, T)
+    elif pattern == "singles":
+        T = 600
+        slots = rng.permutation(NB * B)[:T].astype(np.int32)
+    else:
+        lens = [40, 3, 200, 90]
+        T = 700
+        slots = _prompt_like_slots(rng, lens, B, NB // 2, sum(lens))
+        extra = (NB // 2) * B + rng.permutation((NB // 2) * B)[:T - len(slots)].astype(np.int32)
+        extra[::7] = -1
+        slots = np.concatenate([slots, extra]).astype(np.int32)
+    assert T >= 512
+    case = datagen.CacheCase(name="runs", dtype=dtype, num_tokens=T, num_heads=H, head_size=D, block_size=B,
+                             num_blocks=NB, seed=77)
+    inp = datagen.make_cache_inputs(case)
+    qkv = inp["qkv"]
+    kc_ref, vc_ref = inp["key_caches"][0].copy(), inp["value_caches"][0].copy()
+    valid = np.flatnonzero(slots >= 0)  # the reference has no notion of skipped tokens: leave them out
+    pa_oracle.reshape_and_cache(np.ascontiguousarray(qkv[valid, 1]), np.ascontiguousarray(qkv[valid, 2]), kc_ref, vc_ref,
+                                slots[valid], dtype)
+    qkv_d = _to_dev(qkv, dtype)
+    kc, vc = _to_dev(inp["key_caches"][0], dtype), _to_dev(inp["value_caches"][0], dtype)
+    pkg.cache_ops.reshape_and_cache(qkv_d[:, 1], qkv_d[:, 2], kc, vc, torch.from_numpy(slots).to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(datagen.torch_to_storage(kc, dtype), kc_ref)
+    assert np.array_equal(datagen.torch_to_storage(vc, dtype), vc_ref)
+    # and back: gather returns the rows of every written token
+    out = torch.zeros_like(qkv_d)
+    pkg.cache_ops.gather_cached_kv(out[:, 1], out[:, 2], kc, vc, torch.from_numpy(slots).to(DEV))
+    torch.cuda.synchronize()
+    keep = torch.from_numpy(slots >= 0).to(DEV)
+    assert torch.equal(out[keep][:, 1:], qkv_d[keep][:, 1:])
+
+
+def test_reshape_and_cache_at_prompt_batch_size_round_trip(pkg):
+    """A 16k-token LLaMA-7B prompt batch (32 heads x 128, block 16): scatter,
+    gather back, and compare the value cache with torch's own indexing."""
+    import torch
+    T, H, D, B = 16384, 32, 128, 16
+    NB = T // B + 64
+    g = torch.Generator(device=DEV)
+    g.manual_seed(9)
+    qkv = torch.randn(T, 3, H, D, dtype=torch.float16, device=DEV, generator=g)
+    kc = torch.zeros(NB, H, D // 8, B, 8, dtype=torch.float16, device=DEV)
+    vc = torch.zeros(NB, H, D, B, dtype=torch.float16, device=DEV)
+    table = torch.randperm(NB, device=DEV, generator=g)[:T // B]
+    pos = torch.arange(T, device=DEV)
+    slots = (table[pos // B] * B + pos % B).to(torch.int32)
+    pkg.cache_ops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kc, vc, slots)
+    out = torch.zeros_like(qkv)
+    pkg.cache_ops.gather_cached_kv(out[:, 1], out[:, 2], kc, vc, slots)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 1:], qkv[:, 1:])
+    want_v = torch.zeros_like(vc)
+    want_v[(slots // B).long(), :, :, (slots % B).long()] = qkv[:, 2]
+    assert torch.equal(vc, want_v)
+    want_k = torch.zeros_like(kc)
+    want_k[(slots // B).long(), :, :, (slots % B).long(), :] = qkv[:, 1].reshape(T, H, D // 8, 8)
+    assert torch.equal(kc, want_k)

@@ -127,6 +127,129 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
   }
 }
 
+// ---- reshape_and_cache for prompt-sized batches ---------------------------------
+//
+// A prompt's tokens take consecutive slots, so 16 consecutive tokens fill whole
+// rows of the caches: 16 x 16 B of every key [h][dx] row and B elements of every
+// value [h][d] row.  The kernel above writes those rows one token at a time (a
+// 2-byte value store per element, each its own 32-byte sector write); this one
+// stages 16 tokens x `hs` heads in LDS and writes rows:
+//   keys    lane <-> (token, (h, dx)), token fastest: the 16 lanes of one (h, dx)
+//           cover 256 contiguous bytes when the slots are consecutive;
+//   values  lane <-> (h, d) row; the workgroup walks the chunk's runs of
+//           consecutive slots inside one block (wave-uniform: every lane sees the
+//           same slots) and writes each run's elements of its row with the widest
+//           aligned stores (16 / 8 / 4 / ES bytes).
+// Nothing is assumed about slot_mapping: isolated tokens are runs of one and
+// negative slots are skipped, exactly as in the per-token kernel.
+constexpr int kRunTokens = 16;
+
+template <int ES>
+__global__ void __launch_bounds__(256)
+pa_token_runs_kernel(const char* __restrict__ key, const char* __restrict__ value, char* __restrict__ key_cache,
+                     char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_tokens,
+                     const int num_heads, const int head_size, const int block_size, const int64_t key_stride_bytes,
+                     const int64_t value_stride_bytes, const int hs) {
+  typedef typename Word<ES>::type elem_t;
+  constexpr int X = 16 / ES;
+  constexpr int TC = kRunTokens;
+  extern __shared__ __align__(16) char tile[];
+  __shared__ int slots[TC];
+  const int tid = threadIdx.x;
+  const int t0 = blockIdx.x * TC;
+  const int h0 = blockIdx.y * hs;
+  const int nh = min(hs, num_heads - h0);
+  const int rowb = nh * head_size * ES;  // bytes of one token in a tile
+  char* ktile = tile;
+  char* vtile = tile + TC * hs * head_size * ES;
+
+  if (tid < TC) slots[tid] = t0 + tid < num_tokens ? slot_mapping[t0 + tid] : -1;
+  const int vec_per_tok = rowb / 16;
+  for (int i = tid; i < TC * vec_per_tok; i += 256) {
+    const int tok = i / vec_per_tok, c = i - tok * vec_per_tok;
+    if (t0 + tok < num_tokens) {
+      const int64_t src = (int64_t)h0 * head_size * ES + (int64_t)c * 16;
+      *reinterpret_cast<u32x4*>(ktile + tok * rowb + c * 16) =
+          *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride_bytes + src);
+      *reinterpret_cast<u32x4*>(vtile + tok * rowb + c * 16) =
+          *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride_bytes + src);
+    }
+  }
+  __syncthreads();
+
+  // key cache [blk][h][dx][off][x]
+  const int ndx = head_size / X;
+  for (int i = tid; i < TC * nh * ndx; i += 256) {
+    const int tok = i % TC, hd = i / TC;
+    const int slot = slots[tok];
+    if (slot < 0) continue;
+    const int h = hd / ndx, dx = hd - h * ndx;
+    const int64_t blk = slot / block_size;
+    const int off = slot % block_size;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(ktile + tok * rowb + (h * head_size + dx * X) * ES);
+    store_cache(reinterpret_cast<u32x4*>(key_cache) + ((blk * num_heads + h0 + h) * ndx + dx) * block_size + off, v);
+  }
+
+  // value cache [blk][h][d][off]
+  for (int row = tid; row < nh * head_size; row += 256) {
+    const int h = row / head_size, d = row - h * head_size;
+    int i = 0;
+    while (i < TC) {
+      const int slot = slots[i];
+      if (slot < 0) {
+        ++i;
+        continue;
+      }
+      const int off = slot % block_size;
+      int n = 1;
+      while (i + n < TC && off + n < block_size && slots[i + n] == slot + n) ++n;
+      const int64_t blk = slot / block_size;
+      char* dst = value_cache + ((((blk * num_heads + h0 + h) * head_size + d) * block_size) + off) * (int64_t)ES;
+      const char* src = vtile + i * rowb + row * ES;  // token i + j of this row sits at src + j * rowb
+      int j = 0;
+      while (j < n) {
+        const int at = (off + j) * ES, rem = (n - j) * ES;
+        if (!(at & 15) && rem >= 16) {
+          elem_t tmp[X];
+#pragma unroll
+          for (int e = 0; e < X; e++) tmp[e] = *reinterpret_cast<const elem_t*>(src + (j + e) * rowb);
+          u32x4 v;
+          __builtin_memcpy(&v, tmp, 16);
+          *reinterpret_cast<u32x4*>(dst + j * ES) = v;
+          j += X;
+        } else if (!(at & 7) && rem >= 8) {
+          elem_t tmp[X / 2];
+#pragma unroll
+          for (int e = 0; e < X / 2; e++) tmp[e] = *reinterpret_cast<const elem_t*>(src + (j + e) * rowb);
+          u32x2 v;
+          __builtin_memcpy(&v, tmp, 8);
+          *reinterpret_cast<u32x2*>(dst + j * ES) = v;
+          j += X / 2;
+        } else if (ES == 2 && !(at & 3) && rem >= 4) {
+          elem_t tmp[2];
+          tmp[0] = *reinterpret_cast<const elem_t*>(src + j * rowb);
+          tmp[1] = *reinterpret_cast<const elem_t*>(src + (j + 1) * rowb);
+          uint32_t v;
+          __builtin_memcpy(&v, tmp, 4);
+          *reinterpret_cast<uint32_t*>(dst + j * ES) = v;
+          j += 2;
+        } else {
+          *reinterpret_cast<elem_t*>(dst + j * ES) = *reinterpret_cast<const elem_t*>(src + j * rowb);
+          j += 1;
+        }
+      }
+      i += n;
+    }
+  }
+}
+
+// Token count from which reshape_and_cache uses the run-aware kernel: decode
+// steps (one token per sequence, at most a few hundred) keep the per-token
+// kernel, prompt batches of this size or more are mostly long runs.
+#ifndef PA_CACHE_RUNS_MIN_TOKENS
+#define PA_CACHE_RUNS_MIN_TOKENS 512
+#endif
+
 template <bool GATHER>
 static int token_cache_op(const char* what, void* key, void* value, void* key_cache, void* value_cache,
                           const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
@@ -157,6 +280,23 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
   char* v = static_cast<char*>(value);
   char* kc = static_cast<char*>(key_cache);
   char* vc = static_cast<char*>(value_cache);
+  if (!GATHER && vec && num_tokens >= PA_CACHE_RUNS_MIN_TOKENS && aligned16(value_cache) && (block_size * es) % 16 == 0) {
+    int hs = 256 / head_size;
+    if (hs < 1) hs = 1;
+    if (hs > num_heads) hs = num_heads;
+    const size_t lds = (size_t)2 * kRunTokens * hs * head_size * es;
+    if (lds <= 48 * 1024) {
+      const dim3 grid((num_tokens + kRunTokens - 1) / kRunTokens, (num_heads + hs - 1) / hs);
+      if (es == 2)
+        hipLaunchKernelGGL((pa_token_runs_kernel<2>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping, num_tokens,
+                           num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
+      else
+        hipLaunchKernelGGL((pa_token_runs_kernel<4>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping, num_tokens,
+                           num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
+      PA_CHECK_LAUNCH(what);
+      return PA_OK;
+    }
+  }
 #define PA_LAUNCH_TOKEN(ES, VEC)                                                                              \
   hipLaunchKernelGGL((pa_token_cache_kernel<ES, GATHER, VEC>), dim3(num_tokens, slices), dim3(threads), 0, st, k, v, \
                      kc, vc, slot_mapping, num_heads, head_size, block_size, key_stride * ES, value_stride * ES)
