@@ -243,3 +243,81 @@ def test_reference_call_sequence_through_the_import_shim(pkg):
                                              np.concatenate([[0], np.cumsum(seq_lens)]), scale, "float16")
     got = datagen.torch_to_storage(output, "float16").astype(np.float32)
     assert np.allclose(got, ref.astype(np.float32), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16", "float32"])
+def test_kernel_on_scores_that_drive_the_running_maximum(pkg, dtype):
+    """Score profiles chosen to exercise the lazily updated running maximum of
+    the online softmax: slow ramps (the maximum creeps up by less than the
+    rescale threshold per tile), steep ramps (every tile rescales), isolated
+    jumps at scattered keys, a maximum at the very first key (never rescales
+    again), and large negative scores whose weights underflow.  One head per
+    profile; q = a fixed direction, k_j = that direction times the profile."""
+    import torch
+    D, n = 128, 900
+    rng = np.random.default_rng(3)
+    j = np.arange(n, dtype=np.float64)
+    profiles = [
+        0.02 * j,                                   # +1.3 per 64 keys: long deferral
+        0.2 * j,                                    # +13 per tile: rescale every tile
+        np.where(rng.random(n) < 0.02, 25.0, 0.0) + rng.normal(0, 0.3, n),   # isolated jumps
+        -0.05 * j,                                  # maximum at key 0
+        np.where(j % 97 == 0, 0.0, -80.0),          # everything else underflows
+        rng.normal(0, 4.0, n),                      # plain noise, wide
+    ]
+    H = len(profiles)
+    scale = D ** -0.5
+    u = rng.normal(0, 1, D)
+    u /= np.linalg.norm(u)
+    q = np.zeros((n, H, D))
+    k = np.zeros((n, H, D))
+    for h, prof in enumerate(profiles):
+        q[:, h] = u * 4.0                           # q.k = 4 * amp_j ; times scale -> profile
+        k[:, h] = u[None, :] * (prof[:, None] / (4.0 * scale))
+    v = rng.normal(0, 1, (n, H, D))
+    qkv = datagen.to_storage(np.stack([q, k, v], axis=1).reshape(-1), dtype).reshape(n, 3, H, D)
+    lens = [n - 300, 300]
+    cu = np.array([0, lens[0], n], dtype=np.int32)
+    ref = pa_oracle.multi_query_kv_attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu, scale, dtype)
+    t = datagen.storage_to_torch(qkv.copy(), dtype).to(DEV)
+    out = torch.empty(n, H, D, dtype=t.dtype, device=DEV)
+    pkg._capi.multi_query_kv_attention(out, t[:, 0], t[:, 1], t[:, 2], [int(x) for x in cu], scale)
+    torch.cuda.synchronize()
+    got = datagen.storage_to_float32(datagen.torch_to_storage(out, dtype), dtype).astype(np.float64)
+    want = datagen.storage_to_float32(ref, dtype).astype(np.float64)
+    assert np.all(np.isfinite(got))
+    bound = EPS[dtype] * (2.0 + 3.0 * np.abs(want)) + 2e-6
+    err = np.abs(got - want)
+    assert np.all(err <= bound), f"max err {err.max():.3e} at head {np.unravel_index(err.argmax(), err.shape)[1]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name,H,D,lens", [
+    ("float16", 32, 128, [1024] * 8),
+    ("bfloat16", 32, 80, [700] * 11 + [1]),
+    ("float16", 40, 64, [300, 513, 256, 1000, 255, 257, 2048, 31, 777]),
+    ("float32", 32, 96, [520] * 11),
+])
+def test_kernel_with_256_row_workgroups_against_torch(pkg, dtype_name, H, D, lens):
+    """Batches big enough for the 8-wave (256 query rows) workgroups, with
+    lengths on both sides of their edges, against torch's attention."""
+    import torch
+    import torch.nn.functional as F
+    assert sum((n + 255) // 256 for n in lens) * H >= 1024  # the library's threshold for 8 waves
+    dtype = getattr(torch, dtype_name)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    T = sum(lens)
+    qkv = torch.randn(T, 3, H, D, dtype=dtype, device=DEV, generator=g)
+    q, k, v = qkv.unbind(dim=1)
+    scale = D ** -0.5
+    out = torch.full((T, H, D), float("nan"), dtype=dtype, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(out, q, k, v, lens, scale)
+    tol = {"float16": 3e-3, "bfloat16": 2e-2, "float32": 1e-4}[dtype_name]
+    lo = 0
+    for n in lens:
+        o = F.scaled_dot_product_attention(q[lo:lo + n].transpose(0, 1).float(), k[lo:lo + n].transpose(0, 1).float(),
+                                           v[lo:lo + n].transpose(0, 1).float(), is_causal=True, scale=scale)
+        assert torch.allclose(out[lo:lo + n].float(), o.transpose(0, 1), atol=tol, rtol=tol), n
+        lo += n

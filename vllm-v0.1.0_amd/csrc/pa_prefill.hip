@@ -7,8 +7,8 @@
 // [num_prompt_tokens, H, D] slices of the fused qkv projection (free row
 // strides), the output is dense.
 //
-// One workgroup = 4 waves = 128 query rows of one (prompt, head); each wave
-// owns 32 rows.  Key/value tiles of 64 rows (32 for fp32) go global -> VGPR ->
+// One workgroup = 4 or 8 waves = 128 or 256 query rows of one (prompt, head);
+// each wave owns 32 rows.  Key/value tiles of 64 rows (32 for fp32) go global -> VGPR ->
 // LDS, double buffered, the loads of tile t+1 in flight while tile t is
 // consumed.  Per tile and wave:
 //   S^T = K . Q^T   v_mfma_f32_32x32x16_{f16,bf16}: the KEY index lands on the
@@ -23,6 +23,7 @@
 // fp32 tensors take the same skeleton with v_mfma_f32_32x32x2_f32 (exact fp32
 // products and sums) and element reads of the LDS images.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -41,7 +42,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxSeqs = 256;   // prompts per launch (table rides in the kernel arguments)
 constexpr int kMaxWork = 512;   // (prompt, query block) items per launch
-constexpr int kQBlock = 128;    // query rows per workgroup
 
 struct PromptArgs {
   void* out;
@@ -60,6 +60,7 @@ static_assert(sizeof(PromptArgs) <= 4096, "kernel arguments are limited to 4 KiB
 
 struct OpsF16 {
   static constexpr int ES = 2;
+  static constexpr uint32_t kOnes = 0x3C003C00u;  // two fp16 ones
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -70,6 +71,7 @@ struct OpsF16 {
 };
 struct OpsBF16 {
   static constexpr int ES = 2;
+  static constexpr uint32_t kOnes = 0x3F803F80u;  // two bf16 ones
   static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
@@ -82,8 +84,30 @@ struct OpsF32 {
   static constexpr int ES = 4;
 };
 
-template <typename X, int D>
+// Value of lane l ^ 32 (v_permlane32_swap: no LDS round trip).
+__device__ __forceinline__ float other_half(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // {x[l % 32], x[l % 32 + 32]} in every lane
+  const float lo = __builtin_bit_cast(float, (uint32_t)sw[0]), hi = __builtin_bit_cast(float, (uint32_t)sw[1]);
+  return (threadIdx.x & 32) ? lo : hi;
+}
+
+// How far (log2 units) a row's true maximum may run ahead of the one its
+// weights are scaled by before the accumulators are rescaled.
+constexpr float kDeferLog2 = 5.f;
+
+#ifndef PA_PROMPT_SCHED
+#define PA_PROMPT_SCHED 1
+#endif
+#ifndef PA_PROMPT_PREFETCH
+#define PA_PROMPT_PREFETCH 4
+#endif
+constexpr int kPrefetch = PA_PROMPT_PREFETCH;  // K fragments in flight ahead of their MFMA
+
+template <typename X, int D, int NW>
 struct PromptGeometry {
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int QBLOCK = 32 * NW;     // query rows per workgroup
   static constexpr int ES = X::ES;
   static constexpr bool F32 = ES == 4;
   static constexpr int KT = F32 ? 32 : 64;   // keys per tile
@@ -102,14 +126,18 @@ struct PromptGeometry {
   static constexpr int LDS_BYTES = 2 * BUF;
   static constexpr int CPR = D * ES / 16;    // 16-byte chunks per row
   static constexpr int TOTAL = KT * CPR;
-  static constexpr int NCH = (TOTAL + 255) / 256;
+  static constexpr int NCH = (TOTAL + THREADS - 1) / THREADS;
+  // rows a thread's consecutive chunks are apart, when that is the same for every thread
+  static constexpr bool UNIFORM_ROWS = THREADS % CPR == 0;
+  static constexpr int ROWS_PER_PASS = THREADS / CPR;
   static constexpr int NQ = F32 ? D / 2 : D / 4;  // dwords of q per lane
   static_assert(KBYTES % 16 == 0 && VSTR % 16 == 0, "images must keep 16-byte alignment");
 };
 
-template <typename X, int D>
-__global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
-  using G = PromptGeometry<X, D>;
+template <typename X, int D, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void pa_prompt_kernel(const PromptArgs a) {
+  using G = PromptGeometry<X, D, NW>;
+  constexpr int THREADS = G::THREADS, kQBlock = G::QBLOCK;
   constexpr int ES = G::ES;
   constexpr bool F32 = G::F32;
   constexpr int KT = G::KT, KB = G::KB, DB = G::DB, DP = G::DP;
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
   // Columns D..DP-1 of the V image (head size 80) are never staged: clear
   // both buffers once so the padded rows of O^T stay finite.
   if constexpr (DP != D) {
-    for (int i = tid * 16; i < G::LDS_BYTES; i += 256 * 16) *(u32x4*)(smem + i) = u32x4{0, 0, 0, 0};
+    for (int i = tid * 16; i < G::LDS_BYTES; i += THREADS * 16) *(u32x4*)(smem + i) = u32x4{0, 0, 0, 0};
     __syncthreads();
   }
 
@@ -162,40 +190,53 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
   const unsigned char* kbase = (const unsigned char*)a.k + (int64_t)head * D * ES;
   const unsigned char* vbase = (const unsigned char*)a.v + (int64_t)head * D * ES;
   u32x4 kreg[NCH], vreg[NCH];
+  // Loads never branch on a lane: in the prompt's last tile, rows past its end
+  // (and the idle lanes of a partial chunk pass) re-read the last row, and
+  // commit() replaces what they fetched by zeros.  Everywhere else a thread's
+  // chunks sit at wave-uniform distances, so one 32-bit lane offset serves all
+  // of them and the rest of the address arithmetic is scalar.
+  const uint32_t lane_off_k = (uint32_t)((tid / CPR) * a.k_stride * ES + (tid % CPR) * 16);
+  const uint32_t lane_off_v = (uint32_t)((tid / CPR) * a.v_stride * ES + (tid % CPR) * 16);
   auto issue = [&](int kt) {
+    if (G::UNIFORM_ROWS && kt * KT + KT <= n) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int cidx = tid + 256 * i;
-      const int row = cidx / CPR, ch = cidx - row * CPR;
-      const int key = kt * KT + row;
-      u32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-      if ((TOTAL % 256 == 0 || cidx < TOTAL) && key < n) {  // rows past the prompt read as zero
-        const int64_t tok = t0 + key;
-        kv = *(const u32x4*)(kbase + tok * a.k_stride * ES + ch * 16);
-        vv = *(const u32x4*)(vbase + tok * a.v_stride * ES + ch * 16);
+      for (int i = 0; i < NCH; ++i) {
+        const int64_t tok = t0 + kt * KT + i * G::ROWS_PER_PASS;  // uniform
+        kreg[i] = *(const u32x4*)(kbase + tok * a.k_stride * ES + lane_off_k);
+        vreg[i] = *(const u32x4*)(vbase + tok * a.v_stride * ES + lane_off_v);
       }
-      kreg[i] = kv;
-      vreg[i] = vv;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int cidx = tid + THREADS * i;
+        const int row = min(cidx / CPR, KT - 1), ch = cidx % CPR;
+        const int64_t tok = t0 + min(kt * KT + row, n - 1);
+        kreg[i] = *(const u32x4*)(kbase + tok * a.k_stride * ES + ch * 16);
+        vreg[i] = *(const u32x4*)(vbase + tok * a.v_stride * ES + ch * 16);
+      }
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int kt) {
     unsigned char* kimg = smem + buf * BUF;
     unsigned char* vimg = kimg + KBYTES;
+    const bool tail = kt * KT + KT > n;  // workgroup-uniform
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int cidx = tid + 256 * i;
+      const int cidx = tid + THREADS * i;
       const int row = cidx / CPR, ch = cidx - row * CPR;
-      if (TOTAL % 256 == 0 || cidx < TOTAL) {
+      if (TOTAL % THREADS == 0 || cidx < TOTAL) {
+        u32x4 kv = kreg[i], vv = vreg[i];
+        if (tail && kt * KT + row >= n) kv = vv = u32x4{0, 0, 0, 0};  // rows past the prompt read as zero
         if constexpr (F32) {
           uint32_t* kp = (uint32_t*)(kimg + row * KSTR + ch * 16);
-          kp[0] = kreg[i].x;
-          kp[1] = kreg[i].y;
-          kp[2] = kreg[i].z;
-          kp[3] = kreg[i].w;
+          kp[0] = kv.x;
+          kp[1] = kv.y;
+          kp[2] = kv.z;
+          kp[3] = kv.w;
         } else {
-          *(u32x4*)(kimg + row * KSTR + ch * 16) = kreg[i];
+          *(u32x4*)(kimg + row * KSTR + ch * 16) = kv;
         }
-        *(u32x4*)(vimg + row * VSTR + ch * 16) = vreg[i];
+        *(u32x4*)(vimg + row * VSTR + ch * 16) = vv;
       }
     }
   };
@@ -212,8 +253,26 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
   // 16-column half of the d block (bit 0) and the key quad (bit 1 = hh).
   const int tr_off = (4 * hh + ((lane >> 2) & 3)) * VSTR + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
+  // one (key block, 16-key step) group g = 2 kb + s2: per 32-row block of O^T two
+  // transposed reads (keys 16 s2 + 4 hh + 0..3 and + 8), kept as the low halves
+  // of two registers pairs
+  auto load_vt = [&](const unsigned char* vimg, int g, u32x4 (&dst)[DB][2]) {
+    if constexpr (!F32) {
+      const unsigned char* vrow = vimg + tr_off + g * 16 * VSTR;
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 64 * db));
+        const s16x4 hi =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vrow + 64 * db + 8 * VSTR));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        dst[db][0] = u32x4{l2.x, l2.y, 0, 0};
+        dst[db][1] = u32x4{h2.x, h2.y, 0, 0};
+      }
+    }
+  };
+
   issue(0);
-  commit(0);
+  commit(0, 0);
   __syncthreads();
 
   for (int kt = 0; kt < n_tiles; ++kt) {
@@ -228,24 +287,48 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
       // S^T[key][q]: accumulator register = key row, lane = query row
       f32x16 s[KB];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-        const unsigned char* krow = kimg + (32 * kb + r) * KSTR;
-        if constexpr (F32) {
+      [[maybe_unused]] u32x4 vt[KB * 2][DB][2];  // V^T fragments of one (key block, 16-key step) group
+      if constexpr (F32) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const unsigned char* krow = kimg + (32 * kb + r) * KSTR;
 #pragma unroll
           for (int ks = 0; ks < D / 2; ++ks) {
             const float kv = *(const float*)(krow + (hh * (D / 2) + ks) * 4);
             s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, __builtin_bit_cast(float, qf[ks]), s[kb], 0, 0, 0);
           }
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < D / 16; ++ks) {
-            const u32x4 kv = *(const u32x4*)(krow + (16 * ks + 8 * hh) * 2);
-            const u32x4 qv = {qf[4 * ks], qf[4 * ks + 1], qf[4 * ks + 2], qf[4 * ks + 3]};
-            s[kb] = X::mfma(kv, qv, s[kb]);
-          }
         }
+      } else {
+        // K fragments are fetched kPrefetch k-steps ahead of the MFMA that
+        // consumes them, so the LDS latency overlaps the matrix pipe.
+        constexpr int KS = D / 16, NS = KB * KS;
+        const unsigned char* krow = kimg + r * KSTR + 16 * hh;
+        u32x4 kf[NS];
+#pragma unroll
+        for (int st = 0; st < kPrefetch && st < NS; ++st)
+          kf[st] = *(const u32x4*)(krow + (st / KS) * 32 * KSTR + (st % KS) * 32);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + kPrefetch < NS)
+            kf[st + kPrefetch] = *(const u32x4*)(krow + ((st + kPrefetch) / KS) * 32 * KSTR + ((st + kPrefetch) % KS) * 32);
+          const int ks = st % KS;
+          const u32x4 qv = {qf[4 * ks], qf[4 * ks + 1], qf[4 * ks + 2], qf[4 * ks + 3]};
+          s[st / KS] = X::mfma(kf[st], qv, s[st / KS]);
+        }
+        // the first group of V^T fragments does not depend on the softmax: fetch it now
+        load_vt(vimg, 0, vt[0]);
+#if PA_PROMPT_SCHED
+        __builtin_amdgcn_sched_group_barrier(0x100, kPrefetch, 0);
+#pragma unroll
+        for (int st = 0; st < NS - kPrefetch; ++st) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kPrefetch, 0);
+#endif
       }
 
       // causal mask on the tiles that reach the diagonal (this also hides the
@@ -261,30 +344,37 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
       }
 
       // online softmax, log2 domain.  Every processed tile holds at least one
-      // unmasked key for every row of the wave, so m_new is finite.
+      // unmasked key for every row of the wave, so the tile maximum is finite.
       float mx = s[0][0];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m, mx * a.c);
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      mx = fmaxf(mx, other_half(mx)) * a.c;
+      // The running maximum m follows the true one lazily: it moves only when
+      // some row of the wave outgrows it by more than kDeferLog2, so most tiles
+      // skip the rescale of O^T.  Weights then reach 2^kDeferLog2 instead of 1,
+      // which costs no relative precision in floating point.
+      float alpha = 1.f;
+      if (__builtin_amdgcn_ballot_w64(mx - m > kDeferLog2) != 0) {  // wave-uniform (m = -inf at the first tile)
+        const float m_new = fmaxf(m, mx);
+        alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+      }
       float psum = 0.f;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], a.c, -m_new));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][i], a.c, -m));
           s[kb][i] = p;
-          psum += p;
+          if constexpr (F32) psum += p;
         }
-      l = l * alpha + psum;  // per-lane partial sum: lanes l and l+32 are added at the end
-      m = m_new;
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+      if constexpr (F32) l = l * alpha + psum;  // per-lane partial sum: lanes l and l+32 are added at the end
 
       // O^T[d][q] += V^T[d][key] P^T[key][q]
       if constexpr (F32) {
@@ -300,33 +390,53 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
             }
           }
       } else {
+        f32x16 lsum;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
+        const u32x4 ones = {X::kOnes, X::kOnes, X::kOnes, X::kOnes};
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            // registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
-            const u32x4 pf = {X::pack2(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]), X::pack2(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]),
-                              X::pack2(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]), X::pack2(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7])};
-            const unsigned char* vrow = vimg + tr_off + (32 * kb + 16 * s2) * VSTR;
+        for (int g = 0; g < KB * 2; ++g) {
+          const int kb = g >> 1, s2 = g & 1;
+          if (g + 1 < KB * 2) load_vt(vimg, g + 1, vt[g + 1]);  // next group's fragments behind this group's MFMAs
+          // registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
+          const u32x4 pf = {X::pack2(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]), X::pack2(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]),
+                            X::pack2(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]), X::pack2(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7])};
+          // row sums of the rounded weights: a block of ones as the A operand puts
+          // sum_key P[key][q] (all 64 lanes' keys) into every register of lsum
+          lsum = X::mfma(ones, pf, lsum);
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const u32x4 vfrag = {vt[g][db][0].x, vt[g][db][0].y, vt[g][db][1].x, vt[g][db][1].y};
+            o[db] = X::mfma(vfrag, pf, o[db]);
+          }
+        }
+#if PA_PROMPT_SCHED
+        // order pinned for the scheduler: the next group's transposed reads go out
+        // two at a time between this group's MFMAs
+#pragma unroll
+        for (int g = 0; g < KB * 2; ++g) {
+          if (g + 1 < KB * 2) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) s16x4*)(vrow + 64 * db));
-              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                  (__attribute__((address_space(3))) s16x4*)(vrow + 64 * db + 8 * VSTR));
-              const s16x8 vt = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-              o[db] = X::mfma(__builtin_bit_cast(u32x4, vt), pf, o[db]);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, DB + 1, 0);
           }
+        }
+#endif
+        l = l * alpha + lsum[0];
       }
     }
 
-    if (more) commit(buf ^ 1);
+    if (more) commit(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
   // ---- epilogue --------------------------------------------------------------
-  l += __shfl_xor(l, 32);
+  if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
   if (q0 + r < n) {
     const float inv = 1.f / l;
     unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
@@ -350,34 +460,55 @@ __global__ __launch_bounds__(256, 2) void pa_prompt_kernel(const PromptArgs a) {
 
 // ---- host side -----------------------------------------------------------------
 
-template <typename X, int D>
+template <typename X, int D, int NW>
 int launch_prompt(PromptArgs& args, int num_work, hipStream_t stream) {
-  using G = PromptGeometry<X, D>;
+  using G = PromptGeometry<X, D, NW>;
   static bool configured_on[64] = {};  // per device; benign race: the attribute call is idempotent
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PA_ERR_HIP, "prompt attention: no current device");
   bool& configured = configured_on[dev];
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_prompt_kernel<X, D>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_prompt_kernel<X, D, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (e != hipSuccess) return fail(PA_ERR_HIP, "prompt attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  pa_prompt_kernel<X, D><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(256), G::LDS_BYTES, stream>>>(args);
+  pa_prompt_kernel<X, D, NW><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(G::THREADS), G::LDS_BYTES, stream>>>(args);
   PA_CHECK_LAUNCH("pa_prompt_kernel");
   return PA_OK;
 }
 
-template <typename X>
+template <typename X, int NW>
 int dispatch_head(PromptArgs& args, int num_work, int head_size, hipStream_t stream) {
   switch (head_size) {
-    case 64: return launch_prompt<X, 64>(args, num_work, stream);
-    case 80: return launch_prompt<X, 80>(args, num_work, stream);
-    case 96: return launch_prompt<X, 96>(args, num_work, stream);
-    case 128: return launch_prompt<X, 128>(args, num_work, stream);
+    case 64: return launch_prompt<X, 64, NW>(args, num_work, stream);
+    case 80: return launch_prompt<X, 80, NW>(args, num_work, stream);
+    case 96: return launch_prompt<X, 96, NW>(args, num_work, stream);
+    case 128: return launch_prompt<X, 128, NW>(args, num_work, stream);
     default:
       return fail(PA_ERR_UNSUPPORTED, "prompt attention: unsupported head size %d (supported: 64, 80, 96, 128)", head_size);
   }
+}
+
+template <int NW>
+int dispatch_dtype(PromptArgs& args, int num_work, int head_size, int dtype, hipStream_t stream) {
+  if (dtype == PA_DTYPE_F16) return dispatch_head<OpsF16, NW>(args, num_work, head_size, stream);
+  if (dtype == PA_DTYPE_BF16) return dispatch_head<OpsBF16, NW>(args, num_work, head_size, stream);
+  return dispatch_head<OpsF32, NW>(args, num_work, head_size, stream);
+}
+
+// Query rows per workgroup.  256-row workgroups (8 waves) stage every K/V tile
+// for twice as many rows, which is worth it once the grid still fills the chip
+// several times over; smaller batches keep 128 rows for the finer grain.
+int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
+  static const int forced = [] {
+    const char* e = getenv("PA_PROMPT_WAVES");  // tuning aid: 4 or 8
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 4 || forced == 8) return forced;
+  int64_t big_blocks = 0;
+  for (int s = 0; s < num_seqs; ++s) big_blocks += (cu[s + 1] - cu[s] + 255) / 256;
+  return big_blocks * num_heads >= 4 * 256 ? 8 : 4;
 }
 
 }  // namespace
@@ -397,13 +528,15 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
   const int64_t total = (int64_t)cu_seqlens[num_seqs] - cu_seqlens[0];
   for (int s = 0; s < num_seqs; ++s) {
     PA_REQUIRE(cu_seqlens[s + 1] >= cu_seqlens[s] && cu_seqlens[s] >= 0, "prompt attention: cu_seqlens must be non-decreasing");
-    PA_REQUIRE((int64_t)cu_seqlens[s + 1] - cu_seqlens[s] <= (int64_t)65535 * kQBlock, "prompt attention: prompt %d is too long", s);
+    PA_REQUIRE((int64_t)cu_seqlens[s + 1] - cu_seqlens[s] <= (int64_t)65535 * 128, "prompt attention: prompt %d is too long", s);
   }
   if (total == 0) return PA_OK;
   PA_REQUIRE(out && query && key && value, "prompt attention: null tensor pointer");
   const int64_t row = (int64_t)num_heads * head_size;
   PA_REQUIRE(q_stride >= row && k_stride >= row && v_stride >= row, "prompt attention: row strides are smaller than num_heads * head_size");
   const int es = elem_size(dtype);
+  if ((k_stride | v_stride) * es >= (1ll << 24))
+    return fail(PA_ERR_UNSUPPORTED, "prompt attention: key / value row strides of 16 MiB or more are not supported");
   if (!aligned16(out) || !aligned16(query) || !aligned16(key) || !aligned16(value) || (q_stride * es) % 16 || (k_stride * es) % 16 ||
       (v_stride * es) % 16)
     return fail(PA_ERR_UNSUPPORTED, "prompt attention: tensors and row strides must be 16-byte aligned");
@@ -426,6 +559,8 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
   args.pad_ = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
+  const int waves = choose_waves(cu_seqlens, num_seqs, num_heads);
+  const int qblock = 32 * waves;
   std::vector<uint32_t> work;
   for (int s0 = 0; s0 < num_seqs; s0 += kMaxSeqs) {
     const int ns = std::min(kMaxSeqs, num_seqs - s0);
@@ -433,17 +568,15 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
     work.clear();
     for (int i = 0; i < ns; ++i) {
       const int n = args.cu[i + 1] - args.cu[i];
-      for (int qb = 0; qb * kQBlock < n; ++qb) work.push_back(((uint32_t)i << 16) | (uint32_t)qb);
+      for (int qb = 0; qb * qblock < n; ++qb) work.push_back(((uint32_t)i << 16) | (uint32_t)qb);
     }
     // query blocks far down a prompt see the most keys: start them first
     std::stable_sort(work.begin(), work.end(), [](uint32_t x, uint32_t y) { return (x & 0xffffu) > (y & 0xffffu); });
     for (size_t w0 = 0; w0 < work.size(); w0 += kMaxWork) {
       const int nw = (int)std::min<size_t>(kMaxWork, work.size() - w0);
       std::copy(work.begin() + w0, work.begin() + w0 + nw, args.work);
-      int rc;
-      if (dtype == PA_DTYPE_F16) rc = dispatch_head<OpsF16>(args, nw, head_size, st);
-      else if (dtype == PA_DTYPE_BF16) rc = dispatch_head<OpsBF16>(args, nw, head_size, st);
-      else rc = dispatch_head<OpsF32>(args, nw, head_size, st);
+      const int rc = waves == 8 ? dispatch_dtype<8>(args, nw, head_size, dtype, st)
+                                : dispatch_dtype<4>(args, nw, head_size, dtype, st);
       if (rc != PA_OK) return rc;
     }
   }
