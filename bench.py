@@ -90,6 +90,8 @@ def parse_args(argv=None):
     p.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
     p.add_argument("--dtype", choices=["float16", "bfloat16", "float32"], default="float16")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
+                   help="CPU work the cpu_baseline sample is sized to (one layer of the workload, repeated)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--cpu-plumbing-test", action="store_true",
                    help="run only the multi-process plumbing on CPU (gloo) with a no-op step; used by tests")
@@ -304,11 +306,18 @@ def main(argv=None):
         bt_np, cl_np = block_tables.cpu().numpy(), context_lens.cpu().numpy()
         sm_np = slot_mapping.cpu().numpy()
         pa_oracle.lib()
-        reps = 3  # one layer's caches, walked three times (4 GiB per pass: nothing stays in the CPU caches)
+        # One layer's caches (4 GiB per pass: nothing stays in the CPU caches), walked
+        # until about 12 s of CPU work are on the clock: one untimed pass sizes the sample.
+        def one_layer():
+            pa_oracle.reshape_and_cache(k_np, v_np, kc_np, vc_np, sm_np, dname)
+            return pa_oracle.single_query_cached_kv_attention(q_np, kc_np, vc_np, scale, bt_np, cl_np, dname)
+        t0 = time.perf_counter()
+        ref = one_layer()
+        t_first = time.perf_counter() - t0
+        reps = max(3, min(64, int(args.cpu_baseline_seconds / max(t_first, 1e-3))))
         t0 = time.perf_counter()
         for _ in range(reps):
-            pa_oracle.reshape_and_cache(k_np, v_np, kc_np, vc_np, sm_np, dname)
-            ref = pa_oracle.single_query_cached_kv_attention(q_np, kc_np, vc_np, scale, bt_np, cl_np, dname)
+            ref = one_layer()
         t_layer = (time.perf_counter() - t0) / reps
         extra["cpu_baseline"] = {
             "value": S / (t_layer * L),

@@ -7,7 +7,7 @@ copy the `*_ops*.so` modules and `libpaged_attn_mi355x.so` into a `vllm/`
 package directory, where `from vllm import attention_ops, cache_ops,
 pos_encoding_ops, layernorm_ops, activation_ops` then resolves to them.
 
-Importing the package loads the HIP library and both operator modules and
+Importing the package loads the HIP library and the operator modules and
 fails if any of them has not been built: there is no CPU or eager fallback.
 """
 import torch  # noqa: F401  (libtorch and the HIP runtime must be loaded first)

@@ -1,4 +1,4 @@
-// Glue shared by the two pybind11 operator modules: tensor checks, dtype
+// Glue shared by the pybind11 operator modules: tensor checks, dtype
 // mapping, current-stream lookup and error translation.  The modules keep the
 // reference's Python-visible names and signatures (csrc/attention.cpp:3-19,
 // csrc/cache.cpp:6-47); all device work happens behind the C ABI in
