@@ -21,7 +21,18 @@ cl = torch.full((S,), CTX, dtype=torch.int32, device=dev)
 slots = (bt[:, -1].long() * B + 15).to(torch.int32)
 last = bt[:, -1].long()
 scale = D ** -0.5
-dec = lambda l: pkg.attention_ops.single_query_cached_kv_attention(out, q, kcs[l], vcs[l], scale, bt, cl, B, CTX)
+if len(sys.argv) > 1:  # decode kernel of a `make variant` build: tools/exp_step.py NAME
+    import ctypes
+    vlib = ctypes.CDLL(os.path.join(ROOT, "vllm-v0.1.0_amd", "tune", f"libpa_{sys.argv[1]}.so"))
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    vlib.pa_single_query_cached_kv_attention.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp]
+    def dec(l):
+        rc = vlib.pa_single_query_cached_kv_attention(out.data_ptr(), q.data_ptr(), kcs[l].data_ptr(), vcs[l].data_ptr(), scale,
+                                                      bt.data_ptr(), cl.data_ptr(), S, H, D, B, bps, CTX, q.stride(0), 1,
+                                                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+else:
+    dec = lambda l: pkg.attention_ops.single_query_cached_kv_attention(out, q, kcs[l], vcs[l], scale, bt, cl, B, CTX)
 rsh = lambda l: pkg.cache_ops.reshape_and_cache(k, v, kcs[l], vcs[l], slots)
 
 def measure(name, pre):
