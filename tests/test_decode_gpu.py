@@ -257,3 +257,28 @@ def test_decode_north_star_size_properties(pkg):
             qs, kcs, vcs, scale, tbl, np.array([ctx_list[s]], dtype=np.int32), "float16")
         got = out[s][heads].float().cpu().numpy()
         helpers.assert_close(got, ref.astype(np.float32)[0], 2e-5, 1.5e-3, f"north-star row {s}")
+
+
+@pytest.mark.parametrize("num_heads", [1, 8, 32])
+def test_decode_work_order_covers_every_row_for_any_batch_size(pkg, num_heads):
+    """The kernel walks (sequence, head) rows in a permuted order (groups of
+    sequences dealt round-robin to the XCDs, a partial group last).  Batch
+    sizes on both sides of the group size and of 8 groups, with context
+    lengths sorted in descending order: every row must be written, and match
+    the oracle."""
+    import torch
+    G = max(1, min(16, 128 // num_heads))
+    sizes = sorted({1, G - 1, G, G + 1, 7 * G, 8 * G - 1, 8 * G, 8 * G + 1, 9 * G + 3, 17 * G} - {0})
+    for S in sizes:
+        ctx = sorted((1 + (37 * i) % 90 for i in range(S)), reverse=True)
+        case = datagen.DecodeCase(name=f"order{S}", dtype="float16", num_seqs=S, num_heads=num_heads, head_size=64,
+                                  block_size=16, num_blocks=6 * S + 8, context_lens=ctx, dist="normal",
+                                  tables="permutation", seed=300 + S)
+        inp = datagen.make_decode_inputs(case)
+        out = _run_capi(pkg, inp, case)
+        assert not bool(torch.isnan(out.float()).any()), f"S={S}: rows left unwritten"
+        ref = pa_oracle.single_query_cached_kv_attention(
+            inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+            inp["context_lens"], case.dtype)
+        helpers.assert_close(helpers.out_to_f32(out, case.dtype), datagen.storage_to_float32(ref, case.dtype),
+                             2e-5, 1e-3, f"S={S} H={num_heads}")

@@ -40,6 +40,7 @@ def configs():
     for D in (64, 80, 96):
         add(f"ns_head{D}", D=D)
     add("ns_ragged", ragged=True)
+    add("ns_ragged_sorted", ragged="sorted")
     add("ns_bf16", dt="bf16")
     add("ns_f32", dt="f32", S=128)
     add("c4_llama13b_tp2", H=20)
@@ -58,6 +59,8 @@ def run(cfg, pkg, device, launches=30):
     g.manual_seed(0)
     if cfg["ragged"]:
         ctxs = torch.randint(1, ctx + 1, (S,), generator=g).tolist()
+        if cfg["ragged"] == "sorted":
+            ctxs.sort(reverse=True)
     else:
         ctxs = [ctx] * S
     bps = (ctx + B - 1) // B
