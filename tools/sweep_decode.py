@@ -41,6 +41,8 @@ def configs():
         add(f"ns_head{D}", D=D)
     add("ns_ragged", ragged=True)
     add("ns_ragged_sorted", ragged="sorted")
+    add("ns_outlier_8k", ragged="outlier", ctx=8192)
+    add("ns_outlier_2k_bs64", ragged="outlier", ctx=2048, S=64)
     add("ns_bf16", dt="bf16")
     add("ns_f32", dt="f32", S=128)
     add("c4_llama13b_tp2", H=20)
@@ -61,6 +63,9 @@ def run(cfg, pkg, device, launches=30):
         ctxs = torch.randint(1, ctx + 1, (S,), generator=g).tolist()
         if cfg["ragged"] == "sorted":
             ctxs.sort(reverse=True)
+        elif cfg["ragged"] == "outlier":   # one long sequence among short ones
+            ctxs = [ctx // 32] * S
+            ctxs[S // 2] = ctx
     else:
         ctxs = [ctx] * S
     bps = (ctx + B - 1) // B
