@@ -31,9 +31,15 @@ if len(sys.argv) > 1:  # decode kernel of a `make variant` build: tools/exp_step
                                                       bt.data_ptr(), cl.data_ptr(), S, H, D, B, bps, CTX, q.stride(0), 1,
                                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
+    vlib.pa_reshape_and_cache.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
+    def rsh(l):
+        rc = vlib.pa_reshape_and_cache(k.data_ptr(), v.data_ptr(), kcs[l].data_ptr(), vcs[l].data_ptr(), slots.data_ptr(),
+                                       S, H, D, B, k.stride(0), v.stride(0), 1,
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
 else:
+    rsh = lambda l: pkg.cache_ops.reshape_and_cache(k, v, kcs[l], vcs[l], slots)
     dec = lambda l: pkg.attention_ops.single_query_cached_kv_attention(out, q, kcs[l], vcs[l], scale, bt, cl, B, CTX)
-rsh = lambda l: pkg.cache_ops.reshape_and_cache(k, v, kcs[l], vcs[l], slots)
 
 def measure(name, pre):
     ts = []
@@ -51,3 +57,27 @@ torch.cuda.synchronize()
 measure("A decode alone", lambda l: None)
 measure("B reshape(same layer) then decode", lambda l: rsh(l))
 
+
+def time_reshape():
+    ts = []
+    for i in range(24):
+        l = i % (L - 1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(4): rsh(l)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / 4)
+    print(f"{'reshape_and_cache alone (4 back to back)':50s} median {statistics.median(ts[4:]):7.1f} us")
+time_reshape()
+
+def step_time():
+    def steps(n):
+        for _ in range(n):
+            for l in range(L - 1):
+                rsh(l); dec(l)
+    steps(1); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); steps(6); b.record(); torch.cuda.synchronize()
+    print(f"{'reshape + decode per layer, back to back':50s} {a.elapsed_time(b) * 1e3 / (6 * (L - 1)):7.1f} us")
+step_time()
