@@ -282,3 +282,30 @@ def test_decode_work_order_covers_every_row_for_any_batch_size(pkg, num_heads):
             inp["context_lens"], case.dtype)
         helpers.assert_close(helpers.out_to_f32(out, case.dtype), datagen.storage_to_float32(ref, case.dtype),
                              2e-5, 1e-3, f"S={S} H={num_heads}")
+
+
+@pytest.mark.parametrize("dtype", ["float16", "float32"])
+def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype):
+    """More than 256 rows and a longest context beyond 2048 tokens: the library
+    lists the non-empty (sequence, partition) pairs on the device and a
+    fixed-size grid draws from the list.  Mixed lengths on both sides of the
+    1024-token partition edge, empty contexts, one long outlier; also with an
+    understated max_context_len (the last partition must run to the end)."""
+    import torch
+    ctx = [5000, 100, 2049, 1024, 1025, 0, 1, 16, 2048, 3000, 1023, 77] * 4 + [4097]
+    S, H, D, B = len(ctx), 8, 64, 16
+    case = datagen.DecodeCase(name="list", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                              num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                              tables="permutation", seed=77)
+    inp = datagen.make_decode_inputs(case)
+    assert S * H > 256 and inp["max_context_len"] > 2048
+    assert pkg._capi.decode_workspace_bytes(S, H, D, B, inp["max_context_len"]) > 0
+    ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], dtype), dtype)
+    atol, rtol = helpers.TIGHT[dtype]
+    for announced in (inp["max_context_len"], 3000):
+        inp["max_context_len"] = announced
+        for _ in range(2):  # twice on one workspace: the plan kernel rewinds the counters
+            got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=True), dtype)
+            helpers.assert_close(got, ref, atol, 2 * rtol, f"item list, announced {announced}")

@@ -31,6 +31,8 @@
 
 #include <type_traits>
 
+#include <algorithm>
+
 #include "pa_common.h"
 
 namespace pa {
@@ -133,12 +135,25 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //  again 1 KiB contiguous per instruction.  The probabilities of the lane's X
 //  tokens come from a per-wave LDS strip written by the K-side lanes.
 //
-// PART = false: one workgroup per (sequence, head) walks the whole context and
+// kModeRows : one workgroup per (sequence, head) walks the whole context and
 //   writes the normalised output row.
-// PART = true : one workgroup per (sequence, head, partition) walks
+// kModeParts: one workgroup per (sequence, head, partition) walks
 //   blocks_per_part KV blocks and writes its un-normalised (max, sum,
 //   accumulator) triple to a workspace; pa_decode_merge_kernel combines the
-//   partitions.  This spreads few or very uneven sequences over the whole chip.
+//   partitions.  Every sequence gets the same number of partitions (the empty
+//   ones exit at once): for few sequences, where the chip is otherwise idle.
+// kModeList : for big batches with long contexts.  Partitions of a fixed
+//   length, as many as each sequence needs (at most four).  Every row's first
+//   partition has a workgroup of its own, as in kModeRows;
+//   pa_decode_plan_kernel lists the (sequence, partition >= 1) pairs that
+//   exist from context_lens, and the grid carries one slot per pair that COULD
+//   exist, ahead of the rows: a slot past the end of the list costs one scalar
+//   load.  A sequence of one partition gets its output row written directly,
+//   longer ones go through the workspace and the merge kernel.  One long
+//   sequence among short ones is thereby spread over several workgroups that
+//   start first, instead of setting the launch time alone.
+constexpr int kModeRows = 0, kModeParts = 1, kModeList = 2;
+constexpr int kItemPartBits = 10;  // list items: (sequence << 10) | partition
 
 struct DecodeArgs {
   void* out;
@@ -158,6 +173,9 @@ struct DecodeArgs {
   int num_parts;
   int blocks_per_part;
   int group;  // sequences per work-order group (see the kernel)
+  const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
+  unsigned* counters;     // kModeList: [1] number of pairs ([0] unused)
+  unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
 };
 
 // Build-time knob for A/B runs: 1 = stream every K/V tile with the
@@ -187,9 +205,10 @@ constexpr int decode_min_waves() {
   return 2 * (NK + NV) * 4 <= 64 ? PA_DECODE_MIN_WAVES : 1;
 }
 
-template <typename E, int D, int B, int NW, bool PART>
+template <typename E, int D, int B, int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_decode_kernel(const DecodeArgs a) {
   typedef typename E::storage T;
+  constexpr bool PART = MODE != kModeRows;
   constexpr int X = E::kX;
   constexpr int NDX = D / X;
   constexpr int KJ = 64 / B;
@@ -205,10 +224,6 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   __shared__ float part_m[NW];
   __shared__ float part_l[NW];
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
   // Work order.  The workgroups that share an XCD (and its L2) walk a
   // contiguous range of work items ordered (group of G sequences, head,
   // sequence in group):
@@ -220,19 +235,37 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   //    (block * num_heads + head) * TILE_BYTES: with few heads in flight and
   //    consecutive physical blocks, the loads would fall on a fraction of the
   //    HBM channels (measured: 5.1 instead of 6.7 TB/s).
-  unsigned work = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // kModeList: the first list_slots workgroup ids are slots for the listed
+  // (sequence, partition >= 1) pairs, heads fastest; the rest are the rows'
+  // first partitions in the usual order.  The pairs go first so that the
+  // partitions of long sequences start before the bulk of the batch.
+  int head_l = 0, seq_l = 0;
+  bool listed = false;
+  unsigned row_id = blockIdx.x, row_count = gridDim.x;
   int part = 0;
-  if (PART) {
+  if (MODE == kModeList) {
+    if (blockIdx.x < a.list_slots) {
+      const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
+      if (blockIdx.x >= n_items) return;  // unused slot: one scalar load, then gone
+      const unsigned u = xcd_contiguous(blockIdx.x, n_items);  // an XCD walks consecutive pairs, all heads of each
+      const unsigned pair = a.items[u / (unsigned)a.num_heads];
+      head_l = (int)(u % (unsigned)a.num_heads);
+      seq_l = (int)(pair >> kItemPartBits);
+      part = (int)(pair & ((1u << kItemPartBits) - 1u));
+      listed = true;
+    } else {
+      row_id = blockIdx.x - a.list_slots;
+      row_count = gridDim.x - a.list_slots;
+    }
+  }
+  unsigned work = xcd_contiguous(row_id, row_count);
+  if (MODE == kModeParts) {
     part = work % (unsigned)a.num_parts;
     work /= (unsigned)a.num_parts;
   }
-  //  * the groups are dealt to the XCDs round-robin (position p of the work
-  //    order holds group x + 8 i, x-major), not in contiguous runs of the batch:
-  //    context lengths are often correlated with the position in the batch
-  //    (sorted, or all forks of one long prompt), and a contiguous eighth of
-  //    the batch per XCD then leaves most XCDs idle behind the one that drew
-  //    the long sequences (measured on lengths sorted in descending order:
-  //    5.0 TB/s, against 6.2 TB/s for the same lengths shuffled).
   const unsigned G = a.group;
   const unsigned per_group = G * (unsigned)a.num_heads;
   const unsigned full_groups = (unsigned)a.num_seqs / G;  // a trailing partial group keeps the last place
@@ -252,16 +285,18 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     grp = x + 8u * i;
   }
   const unsigned gsize = min(G, (unsigned)a.num_seqs - grp * G);  // the last group may be short
-  const int head = in_grp / gsize;
-  const int seq = grp * G + (in_grp - head * gsize);
+  const int head = listed ? head_l : (int)(in_grp / gsize);
+  const int seq = listed ? seq_l : (int)(grp * G + (in_grp - (in_grp / gsize) * gsize));
 
   const int ctx = a.context_lens[seq];
   const int nblk_seq = (ctx + B - 1) / B;
+  // kModeList: a sequence that fits one partition is finished here, without the workspace
+  const bool direct = !PART || (MODE == kModeList && nblk_seq <= a.blocks_per_part);
   const int blk_begin = PART ? part * a.blocks_per_part : 0;
   // the last partition runs to the end of the context even if the context is
   // longer than the max_context_len the partition plan was made for
   const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + a.blocks_per_part) : nblk_seq;
-  if (PART && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
+  if (MODE == kModeParts && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
   const int* __restrict__ table = a.block_tables + (int64_t)seq * a.max_blocks_per_seq;
   // Neighbouring sequences' tables, to spot shared physical blocks (forked
   // sequences keep the parent's blocks and sit next to it in the batch).
@@ -480,7 +515,7 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     L = __builtin_fmaf(part_l[w], f[w], L);
   }
   const int64_t row = (int64_t)seq * a.num_heads + head;
-  if (PART) {
+  if (!direct) {
     const int64_t slot = row * a.num_parts + part;
     for (int d = tid; d < D; d += NW * 64) {
       float o = 0.f;
@@ -504,12 +539,53 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   }
 }
 
+// Lists the (sequence, partition >= 1) pairs of a batch for kModeList: one
+// workgroup scans context_lens 256 sequences at a time.  A sequence has
+// ceil(blocks / blocks_per_part) partitions, at most max_parts (the last
+// partition then runs to the end of the context).
+__global__ void __launch_bounds__(256)
+pa_decode_plan_kernel(const int* __restrict__ context_lens, const int num_seqs, const int block_size,
+                      const int blocks_per_part, const int max_parts, uint32_t* __restrict__ items,
+                      unsigned* __restrict__ counters) {
+  __shared__ unsigned scan[256];
+  __shared__ unsigned base;
+  const int tid = threadIdx.x;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < num_seqs; s0 += 256) {
+    const int seq = s0 + tid;
+    unsigned extra = 0;
+    if (seq < num_seqs) {
+      const int nblk = (context_lens[seq] + block_size - 1) / block_size;
+      extra = (unsigned)(min(max((nblk + blocks_per_part - 1) / blocks_per_part, 1), max_parts) - 1);
+    }
+    scan[tid] = extra;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
+      const unsigned add = tid >= off ? scan[tid - off] : 0u;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const unsigned first = base + scan[tid] - extra;
+    for (unsigned p = 0; p < extra; p++) items[first + p] = ((uint32_t)seq << kItemPartBits) | (p + 1u);
+    __syncthreads();
+    if (tid == 255) base += scan[255];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counters[0] = 0u;
+    counters[1] = base;
+  }
+}
+
 // Combines the partitions of one (sequence, head): one wave per output row.
 // The (max, sum) pairs are read one partition per lane and reduced across the
 // wave; the accumulator rows are then summed with lanes along d, all loads of
 // a group of partitions issued before the first use.
 template <typename E, int D>
-__global__ void __launch_bounds__(64) pa_decode_merge_kernel(const DecodeArgs a, const int tokens_per_part) {
+__global__ void __launch_bounds__(64)
+pa_decode_merge_kernel(const DecodeArgs a, const int tokens_per_part, const int skip_single) {
   typedef typename E::storage T;
   constexpr int PER = (D + 63) / 64;
   const int lane = threadIdx.x;
@@ -517,6 +593,7 @@ __global__ void __launch_bounds__(64) pa_decode_merge_kernel(const DecodeArgs a,
   const int seq = (int)(row / a.num_heads);
   const int ctx = a.context_lens[seq];
   const int nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
+  if (skip_single && nparts <= 1) return;  // kModeList wrote this row directly
   const float* __restrict__ ml = a.ws_ml + 2 * row * a.num_parts;
   const float* __restrict__ wacc = a.ws_acc + row * a.num_parts * D;
 
@@ -576,13 +653,22 @@ static int launch(const DecodeArgs& a, int tokens_per_part, hipStream_t stream) 
   constexpr int NW = kNumWaves;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
   if (a.num_parts <= 1) {
-    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, false>), dim3(rows), dim3(NW * 64), 0, stream, a);
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeRows>), dim3(rows), dim3(NW * 64), 0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel launch");
-  } else {
-    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, true>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64), 0,
-                       stream, a);
+  } else if (a.items == nullptr) {
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeParts>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64),
+                       0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (partitioned) launch");
-    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part);
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, 0);
+    PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
+  } else {
+    hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(256), 0, stream, a.context_lens, a.num_seqs, B,
+                       a.blocks_per_part, a.num_parts, const_cast<uint32_t*>(a.items), a.counters);
+    PA_CHECK_LAUNCH("pa_decode_plan_kernel launch");
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeList>), dim3(a.list_slots + rows), dim3(NW * 64), 0, stream,
+                       a);
+    PA_CHECK_LAUNCH("pa_decode_kernel (item list) launch");
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, 1);
     PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   }
   return PA_OK;
@@ -618,15 +704,21 @@ static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, hipStream_t
 struct PartitionPlan {
   int num_parts;
   int blocks_per_part;
-  int group;  // sequences per work-order group (see the kernel)
+  bool list;  // kModeList: partitions of a fixed length, as many as each sequence needs
 };
+
+// kModeList: partitions of at least this many tokens, at most kListMaxParts of
+// them; batches whose longest context is at most twice that keep one workgroup
+// per row.
+constexpr int kListPartTokens = 1024;
+constexpr int kListMaxParts = 4;
 
 static PartitionPlan plan_partitions(int num_seqs, int num_heads, int block_size, int max_context_len) {
   const int64_t rows = (int64_t)num_seqs * num_heads;
   const int max_blocks = (max_context_len + block_size - 1) / block_size;
   int min_blocks = kNumWaves;
   while (min_blocks * block_size < 64) min_blocks *= 2;
-  PartitionPlan p = {1, max_blocks > 0 ? max_blocks : 1};
+  PartitionPlan p = {1, max_blocks > 0 ? max_blocks : 1, false};
   static const int forced = [] {
     const char* e = getenv("PA_DECODE_FORCE_PARTS");  // tuning aid only
     return e ? atoi(e) : 0;
@@ -634,19 +726,34 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int block_size
   const int64_t target_wgs = 1024;
   const bool worth_it = rows <= 64 || (rows <= 256 && (int64_t)max_context_len * rows >= 256 * 1024);
   int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
+  static const int list_mode = [] {
+    const char* e = getenv("PA_DECODE_LIST");  // tuning aid only: 0 = never, 1 = whenever a context can exceed one partition
+    return e ? atoi(e) : -1;
+  }();
+  int list_bpp = std::max(kListPartTokens / block_size, (max_blocks + kListMaxParts - 1) / kListMaxParts);
+  list_bpp = (list_bpp + kNumWaves - 1) / kNumWaves * kNumWaves;
+  const bool long_contexts = list_mode == 1 ? max_blocks > list_bpp : max_context_len > 2 * kListPartTokens;
+  if (want <= 1 && list_mode != 0 && long_contexts && num_seqs < (1 << (32 - kItemPartBits))) {
+    const int parts = (max_blocks + list_bpp - 1) / list_bpp;
+    if (parts > 1 && rows * parts < (1ll << 31)) return PartitionPlan{parts, list_bpp, true};
+  }
   if (want <= 1 || max_blocks <= min_blocks) return p;
   int bpp = (max_blocks + want - 1) / want;
   if (bpp < min_blocks) bpp = min_blocks;
   bpp = (bpp + kNumWaves - 1) / kNumWaves * kNumWaves;  // whole rounds of the waves
   p.blocks_per_part = bpp;
   p.num_parts = (max_blocks + bpp - 1) / bpp;
-  if (p.num_parts <= 1) p = PartitionPlan{1, max_blocks};
+  if (p.num_parts <= 1) p = PartitionPlan{1, max_blocks, false};
   return p;
 }
 
-static size_t workspace_bytes_for(int64_t rows, int num_parts, int head_size) {
-  // accumulators [rows * parts][D] then (max, sum) pairs [rows * parts][2], fp32
-  return (size_t)rows * num_parts * (head_size + 2) * sizeof(float);
+// Workspace: accumulators [rows * parts][D], then (max, sum) pairs
+// [rows * parts][2], fp32; kModeList appends the item list [num_seqs * parts]
+// and the two counters.
+static size_t workspace_bytes_for(int64_t rows, int num_parts, int head_size, int64_t list_seqs) {
+  size_t n = (size_t)rows * num_parts * (head_size + 2) * sizeof(float);
+  if (list_seqs > 0) n += (size_t)list_seqs * num_parts * sizeof(uint32_t) + 2 * sizeof(unsigned);
+  return n;
 }
 
 static int decode_entry(void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
@@ -681,6 +788,9 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.context_lens = context_lens;
   a.ws_acc = nullptr;
   a.ws_ml = nullptr;
+  a.items = nullptr;
+  a.counters = nullptr;
+  a.list_slots = 0;
   a.q_stride = q_stride;
   a.scale_log2e = scale * 1.4426950408889634f;
   a.num_seqs = num_seqs;
@@ -696,11 +806,17 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     const PartitionPlan p = plan_partitions(num_seqs, num_heads, block_size, max_context_len);
     if (p.num_parts > 1 && rows * p.num_parts < (1ll << 31) &&
-        workspace_bytes_for(rows, p.num_parts, head_size) <= workspace_bytes) {
+        workspace_bytes_for(rows, p.num_parts, head_size, p.list ? num_seqs : 0) <= workspace_bytes) {
       a.num_parts = p.num_parts;
       a.blocks_per_part = p.blocks_per_part;
       a.ws_acc = static_cast<float*>(workspace);
       a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
+      if (p.list) {
+        uint32_t* tail = reinterpret_cast<uint32_t*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
+        a.items = tail;
+        a.counters = tail + (size_t)num_seqs * p.num_parts;
+        a.list_slots = (unsigned)(rows * (p.num_parts - 1));
+      }
     }
   }
   const int tokens_per_part = a.blocks_per_part * block_size;
@@ -728,7 +844,7 @@ extern "C" size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int hea
   if (num_seqs <= 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0 || max_context_len <= 0) return 0;
   const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, block_size, max_context_len);
   if (p.num_parts <= 1) return 0;
-  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p.num_parts, head_size);
+  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p.num_parts, head_size, p.list ? num_seqs : 0);
 }
 
 extern "C" int pa_single_query_cached_kv_attention_ws(
