@@ -24,6 +24,12 @@ SHAPES = {
     "north_star": dict(S=256, H=32, D=128, B=16, ctx=1024, ragged=False),
     "c2": dict(S=256, H=12, D=64, B=16, ctx=1024, ragged=False),
     "ragged": dict(S=256, H=32, D=128, B=16, ctx=1024, ragged=True),
+    "head96": dict(S=256, H=32, D=96, B=16, ctx=1024, ragged=False),
+    "head80": dict(S=256, H=32, D=80, B=16, ctx=1024, ragged=False),
+    "head64": dict(S=256, H=32, D=64, B=16, ctx=1024, ragged=False),
+    "c2_ragged": dict(S=256, H=12, D=64, B=16, ctx=1024, ragged=True),
+    "c2_block8": dict(S=256, H=12, D=64, B=8, ctx=1024, ragged=False),
+    "c2_bs16": dict(S=16, H=12, D=64, B=16, ctx=1024, ragged=False),
     "bs16": dict(S=16, H=32, D=128, B=16, ctx=1024, ragged=False),
     "bs1": dict(S=1, H=32, D=128, B=16, ctx=1024, ragged=False),
     "block8": dict(S=256, H=32, D=128, B=8, ctx=1024, ragged=False),
