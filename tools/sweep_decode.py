@@ -49,6 +49,12 @@ def configs():
     add("ns_f32", dt="f32", S=128)
     add("c4_llama13b_tp2", H=20)
     add("c5_neox20b_tp4_n3", H=16, D=96, share=3)
+    add("tp8_llama65b", H=8)
+    add("opt30b_h56", H=56)
+    add("h64", H=64, S=128)
+    add("h1", H=1, S=256, ctx=2048)
+    add("bs100_h40", H=40, S=100)
+    add("opt2.7b_h32_d80_bs37", H=32, D=80, S=37)
     add("c2_block8", H=12, D=64, B=8)
     add("c2_ragged", H=12, D=64, ragged=True)
     return c
