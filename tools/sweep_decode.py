@@ -33,6 +33,10 @@ def configs():
         add(f"ns_ctx{ctx}", ctx=ctx)
     for S in (1, 4, 16, 64, 128):
         add(f"ns_bs{S}", S=S)
+    add("tiny_bs1_ctx64", S=1, ctx=64)
+    add("tiny_bs4_ctx128", S=4, ctx=128)
+    add("tiny_bs4_ctx512", S=4, ctx=512)
+    add("tiny_bs16_ctx128", S=16, ctx=128)
     add("long_bs1_ctx16k", S=1, ctx=16384)
     add("long_bs4_ctx8k", S=4, ctx=8192)
     for B in (8, 32):
