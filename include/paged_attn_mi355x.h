@@ -94,7 +94,10 @@ int pa_single_query_cached_kv_attention(
  * aligned, contents irrelevant, may be reused by the next call on the same
  * stream) the library may split every sequence's context into partitions that
  * run as separate workgroups and are combined by a second kernel; it does so
- * when num_seqs * num_heads alone cannot fill the GPU (small batches).  With
+ * when num_seqs * num_heads alone cannot fill the GPU (small batches), and for
+ * big batches whose longest context exceeds 2048 tokens (there, the partitions
+ * that exist are listed on the device first, so that one long sequence among
+ * short ones does not set the launch time alone).  With
  * workspace == NULL, or one that is too small, it behaves exactly like
  * pa_single_query_cached_kv_attention.  Results agree with the unsplit kernel
  * up to fp32 summation order.  No counterpart in the reference, whose kernel

@@ -2,7 +2,7 @@
 include/paged_attn_mi355x.h).
 
 This is the raw boundary: pointers and sizes only.  The torch-facing operator
-modules (`attention_ops`, `cache_ops`) are separate pybind11 extensions on top
+modules (`attention_ops`, `cache_ops`, `pos_encoding_ops`, `layernorm_ops`, `activation_ops`) are separate pybind11 extensions on top
 of the same library; this binding exists so that the C ABI itself can be
 driven and tested from Python exactly as a foreign-language host would drive
 it.  There is no fallback: if the library is missing, importing fails.
