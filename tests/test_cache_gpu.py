@@ -312,6 +312,7 @@ def test_reshape_and_cache_prompt_sized_batches_match_oracle(pkg, dtype, H, D, B
     torch.cuda.synchronize()
     keep = torch.from_numpy(slots >= 0).to(DEV)
     assert torch.equal(out[keep][:, 1:], qkv_d[keep][:, 1:])
+    assert torch.count_nonzero(out[~keep]) == 0 and torch.count_nonzero(out[:, 0]) == 0  # nothing else is touched
 
 
 def test_reshape_and_cache_at_prompt_batch_size_round_trip(pkg):

@@ -127,7 +127,7 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
   }
 }
 
-// ---- reshape_and_cache for prompt-sized batches ---------------------------------
+// ---- reshape_and_cache / gather_cached_kv for prompt-sized batches --------------
 //
 // A prompt's tokens take consecutive slots, so 16 consecutive tokens fill whole
 // rows of the caches: 16 x 16 B of every key [h][dx] row and B elements of every
@@ -141,12 +141,13 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
 //           same slots) and writes each run's elements of its row with the widest
 //           aligned stores (16 / 8 / 4 / ES bytes).
 // Nothing is assumed about slot_mapping: isolated tokens are runs of one and
-// negative slots are skipped, exactly as in the per-token kernel.
+// negative slots are skipped, exactly as in the per-token kernel.  GATHER runs
+// the same walk the other way: cache rows -> LDS -> token rows.
 constexpr int kRunTokens = 16;
 
-template <int ES>
+template <int ES, bool GATHER>
 __global__ void __launch_bounds__(256)
-pa_token_runs_kernel(const char* __restrict__ key, const char* __restrict__ value, char* __restrict__ key_cache,
+pa_token_runs_kernel(char* __restrict__ key, char* __restrict__ value, char* __restrict__ key_cache,
                      char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_tokens,
                      const int num_heads, const int head_size, const int block_size, const int64_t key_stride_bytes,
                      const int64_t value_stride_bytes, const int hs) {
@@ -162,19 +163,29 @@ pa_token_runs_kernel(const char* __restrict__ key, const char* __restrict__ valu
   const int rowb = nh * head_size * ES;  // bytes of one token in a tile
   char* ktile = tile;
   char* vtile = tile + TC * hs * head_size * ES;
+  const int vec_per_tok = rowb / 16;
 
   if (tid < TC) slots[tid] = t0 + tid < num_tokens ? slot_mapping[t0 + tid] : -1;
-  const int vec_per_tok = rowb / 16;
-  for (int i = tid; i < TC * vec_per_tok; i += 256) {
-    const int tok = i / vec_per_tok, c = i - tok * vec_per_tok;
-    if (t0 + tok < num_tokens) {
-      const int64_t src = (int64_t)h0 * head_size * ES + (int64_t)c * 16;
-      *reinterpret_cast<u32x4*>(ktile + tok * rowb + c * 16) =
-          *reinterpret_cast<const u32x4*>(key + (int64_t)(t0 + tok) * key_stride_bytes + src);
-      *reinterpret_cast<u32x4*>(vtile + tok * rowb + c * 16) =
-          *reinterpret_cast<const u32x4*>(value + (int64_t)(t0 + tok) * value_stride_bytes + src);
+  // token rows <-> LDS tiles, 16-byte vectors, coalesced on the token side
+  auto token_rows = [&](bool to_tile) {
+    for (int i = tid; i < TC * vec_per_tok; i += 256) {
+      const int tok = i / vec_per_tok, c = i - tok * vec_per_tok;
+      if (t0 + tok >= num_tokens) continue;
+      const int64_t at = (int64_t)h0 * head_size * ES + (int64_t)c * 16;
+      u32x4* kg = reinterpret_cast<u32x4*>(key + (int64_t)(t0 + tok) * key_stride_bytes + at);
+      u32x4* vg = reinterpret_cast<u32x4*>(value + (int64_t)(t0 + tok) * value_stride_bytes + at);
+      u32x4* kl = reinterpret_cast<u32x4*>(ktile + tok * rowb + c * 16);
+      u32x4* vl = reinterpret_cast<u32x4*>(vtile + tok * rowb + c * 16);
+      if (to_tile) {
+        *kl = *kg;
+        *vl = *vg;
+      } else if (slots[tok] >= 0) {  // tokens without a slot keep their rows
+        *kg = *kl;
+        *vg = *vl;
+      }
     }
-  }
+  };
+  if (!GATHER) token_rows(true);
   __syncthreads();
 
   // key cache [blk][h][dx][off][x]
@@ -186,8 +197,10 @@ pa_token_runs_kernel(const char* __restrict__ key, const char* __restrict__ valu
     const int h = hd / ndx, dx = hd - h * ndx;
     const int64_t blk = slot / block_size;
     const int off = slot % block_size;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(ktile + tok * rowb + (h * head_size + dx * X) * ES);
-    store_cache(reinterpret_cast<u32x4*>(key_cache) + ((blk * num_heads + h0 + h) * ndx + dx) * block_size + off, v);
+    u32x4* kl = reinterpret_cast<u32x4*>(ktile + tok * rowb + (h * head_size + dx * X) * ES);
+    u32x4* kc = reinterpret_cast<u32x4*>(key_cache) + ((blk * num_heads + h0 + h) * ndx + dx) * block_size + off;
+    if (GATHER) *kl = *kc;
+    else store_cache(kc, *kl);
   }
 
   // value cache [blk][h][d][off]
@@ -204,46 +217,55 @@ pa_token_runs_kernel(const char* __restrict__ key, const char* __restrict__ valu
       int n = 1;
       while (i + n < TC && off + n < block_size && slots[i + n] == slot + n) ++n;
       const int64_t blk = slot / block_size;
-      char* dst = value_cache + ((((blk * num_heads + h0 + h) * head_size + d) * block_size) + off) * (int64_t)ES;
-      const char* src = vtile + i * rowb + row * ES;  // token i + j of this row sits at src + j * rowb
+      char* crow = value_cache + ((((blk * num_heads + h0 + h) * head_size + d) * block_size) + off) * (int64_t)ES;
+      char* lrow = vtile + i * rowb + row * ES;  // token i + j of this row sits at lrow + j * rowb
       int j = 0;
       while (j < n) {
         const int at = (off + j) * ES, rem = (n - j) * ES;
-        if (!(at & 15) && rem >= 16) {
-          elem_t tmp[X];
+        // widest aligned piece of the cache row: 16, 8, 4 (16-bit types) or ES bytes
+        const int bytes = (!(at & 15) && rem >= 16) ? 16 : (!(at & 7) && rem >= 8) ? 8 : (ES == 2 && !(at & 3) && rem >= 4) ? 4 : ES;
+        const int cnt = bytes / ES;
+        elem_t tmp[X];
+        if (GATHER) {
+          if (bytes == 16) __builtin_memcpy(tmp, crow + j * ES, 16);
+          else if (bytes == 8) __builtin_memcpy(tmp, crow + j * ES, 8);
+          else if (bytes == 4) __builtin_memcpy(tmp, crow + j * ES, 4);
+          else tmp[0] = *reinterpret_cast<const elem_t*>(crow + j * ES);
 #pragma unroll
-          for (int e = 0; e < X; e++) tmp[e] = *reinterpret_cast<const elem_t*>(src + (j + e) * rowb);
-          u32x4 v;
-          __builtin_memcpy(&v, tmp, 16);
-          *reinterpret_cast<u32x4*>(dst + j * ES) = v;
-          j += X;
-        } else if (!(at & 7) && rem >= 8) {
-          elem_t tmp[X / 2];
-#pragma unroll
-          for (int e = 0; e < X / 2; e++) tmp[e] = *reinterpret_cast<const elem_t*>(src + (j + e) * rowb);
-          u32x2 v;
-          __builtin_memcpy(&v, tmp, 8);
-          *reinterpret_cast<u32x2*>(dst + j * ES) = v;
-          j += X / 2;
-        } else if (ES == 2 && !(at & 3) && rem >= 4) {
-          elem_t tmp[2];
-          tmp[0] = *reinterpret_cast<const elem_t*>(src + j * rowb);
-          tmp[1] = *reinterpret_cast<const elem_t*>(src + (j + 1) * rowb);
-          uint32_t v;
-          __builtin_memcpy(&v, tmp, 4);
-          *reinterpret_cast<uint32_t*>(dst + j * ES) = v;
-          j += 2;
+          for (int e = 0; e < X; e++)
+            if (e < cnt) *reinterpret_cast<elem_t*>(lrow + (j + e) * rowb) = tmp[e];
         } else {
-          *reinterpret_cast<elem_t*>(dst + j * ES) = *reinterpret_cast<const elem_t*>(src + j * rowb);
-          j += 1;
+#pragma unroll
+          for (int e = 0; e < X; e++)
+            if (e < cnt) tmp[e] = *reinterpret_cast<const elem_t*>(lrow + (j + e) * rowb);
+          if (bytes == 16) {
+            u32x4 v;
+            __builtin_memcpy(&v, tmp, 16);
+            *reinterpret_cast<u32x4*>(crow + j * ES) = v;
+          } else if (bytes == 8) {
+            u32x2 v;
+            __builtin_memcpy(&v, tmp, 8);
+            *reinterpret_cast<u32x2*>(crow + j * ES) = v;
+          } else if (bytes == 4) {
+            uint32_t v;
+            __builtin_memcpy(&v, tmp, 4);
+            *reinterpret_cast<uint32_t*>(crow + j * ES) = v;
+          } else {
+            *reinterpret_cast<elem_t*>(crow + j * ES) = tmp[0];
+          }
         }
+        j += cnt;
       }
       i += n;
     }
   }
+  if (GATHER) {
+    __syncthreads();
+    token_rows(false);
+  }
 }
 
-// Token count from which reshape_and_cache uses the run-aware kernel: decode
+// Token count from which reshape_and_cache / gather_cached_kv use the run-aware kernel: decode
 // steps (one token per sequence, at most a few hundred) keep the per-token
 // kernel, prompt batches of this size or more are mostly long runs.
 #ifndef PA_CACHE_RUNS_MIN_TOKENS
@@ -280,7 +302,7 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
   char* v = static_cast<char*>(value);
   char* kc = static_cast<char*>(key_cache);
   char* vc = static_cast<char*>(value_cache);
-  if (!GATHER && vec && num_tokens >= PA_CACHE_RUNS_MIN_TOKENS && aligned16(value_cache) && (block_size * es) % 16 == 0) {
+  if (vec && num_tokens >= PA_CACHE_RUNS_MIN_TOKENS && aligned16(value_cache) && (block_size * es) % 16 == 0) {
     int hs = 256 / head_size;
     if (hs < 1) hs = 1;
     if (hs > num_heads) hs = num_heads;
@@ -288,11 +310,11 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
     if (lds <= 48 * 1024) {
       const dim3 grid((num_tokens + kRunTokens - 1) / kRunTokens, (num_heads + hs - 1) / hs);
       if (es == 2)
-        hipLaunchKernelGGL((pa_token_runs_kernel<2>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping, num_tokens,
-                           num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
+        hipLaunchKernelGGL((pa_token_runs_kernel<2, GATHER>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping,
+                           num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
       else
-        hipLaunchKernelGGL((pa_token_runs_kernel<4>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping, num_tokens,
-                           num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
+        hipLaunchKernelGGL((pa_token_runs_kernel<4, GATHER>), grid, dim3(256), lds, st, k, v, kc, vc, slot_mapping,
+                           num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es, hs);
       PA_CHECK_LAUNCH(what);
       return PA_OK;
     }
