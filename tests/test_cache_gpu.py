@@ -340,3 +340,34 @@ def test_reshape_and_cache_at_prompt_batch_size_round_trip(pkg):
     want_k = torch.zeros_like(kc)
     want_k[(slots // B).long(), :, :, (slots % B).long(), :] = qkv[:, 1].reshape(T, H, D // 8, 8)
     assert torch.equal(kc, want_k)
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned", "pageable"])
+def test_swap_blocks_many_scattered_blocks(pkg, pinned):
+    """Enough scattered blocks for the one-launch kernel path (pinned host memory
+    is addressed by the device directly); pageable host memory cannot be and takes
+    the per-run copies.  Both directions, on a side stream, untouched blocks intact."""
+    import torch
+    H, D, B, NBG, NBC, n = 4, 64, 16, 300, 120, 70
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gpu = torch.randn(NBG, H, D // 8, B, 8, dtype=torch.float16, device=DEV)
+    cpu = torch.full((NBC, H, D // 8, B, 8), -1.0, dtype=torch.float16)
+    if pinned:
+        cpu = cpu.pin_memory()
+    src = torch.randperm(NBG, generator=g)[:n].tolist()
+    dst = torch.randperm(NBC, generator=g)[:n].tolist()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        pkg.cache_ops.swap_blocks(gpu, cpu, dict(zip(src, dst)))
+    side.synchronize()
+    want = torch.full_like(cpu, -1.0)
+    want[dst] = gpu[src].cpu()
+    assert torch.equal(cpu, want)
+    # and back into other GPU blocks
+    back = torch.randperm(NBG, generator=g)[:n].tolist()
+    before = gpu.clone()
+    with torch.cuda.stream(side):
+        pkg.cache_ops.swap_blocks(cpu, gpu, dict(zip(dst, back)))
+    side.synchronize()
+    before[back] = cpu[dst].to(DEV)
+    assert torch.equal(gpu, before)

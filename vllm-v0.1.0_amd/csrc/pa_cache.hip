@@ -3,6 +3,8 @@
 // csrc/cache_kernels.cu of vLLM v0.1.0.  All of them are byte movers, so they
 // are written over raw 16-byte vectors and element-sized words; the element
 // type only enters through its size.  Offsets are 64-bit throughout.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "pa_common.h"
@@ -377,6 +379,50 @@ pa_copy_blocks_kernel(const CopyTable tab, const int64_t block_bytes, const int 
   for (; i < hi; i += 256) store_cache(&d[i], s[i]);
 }
 
+// swap_blocks through a kernel: pinned host memory is mapped into the device's
+// address space, so one launch can move up to kCopyMaxPairs scattered blocks over
+// PCIe / xGMI instead of one hipMemcpyAsync per run of blocks (the host-side cost
+// of thousands of small copies is what bounds a swap of scattered blocks).
+// grid = (pairs, splits).
+struct SwapTable {
+  const char* src;
+  char* dst;
+  int64_t src_block[kCopyMaxPairs];
+  int64_t dst_block[kCopyMaxPairs];
+};
+
+__global__ void __launch_bounds__(256) pa_swap_blocks_kernel(const SwapTable tab, const int64_t block_bytes, const int splits) {
+  const int pair = blockIdx.x, part = blockIdx.y;
+  const u32x4* __restrict__ s = reinterpret_cast<const u32x4*>(tab.src + tab.src_block[pair] * block_bytes);
+  u32x4* __restrict__ d = reinterpret_cast<u32x4*>(tab.dst + tab.dst_block[pair] * block_bytes);
+  const int64_t nwords = block_bytes / 16;
+  const int64_t per = (nwords + splits - 1) / splits;
+  const int64_t lo = per * part;
+  const int64_t hi = lo + per < nwords ? lo + per : nwords;
+  int64_t i = lo + threadIdx.x;
+  for (; i + 3 * 256 < hi; i += 4 * 256) {
+    const u32x4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+    d[i] = a;
+    d[i + 256] = b;
+    d[i + 512] = c;
+    d[i + 768] = e;
+  }
+  for (; i < hi; i += 256) d[i] = s[i];
+}
+
+// Device-visible alias of a pointer that a kernel is about to dereference:
+// device memory as it is, host memory only if it is pinned and mapped.
+static char* device_alias(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // unregistered (pageable) host memory
+    return nullptr;
+  }
+  if (attr.type == hipMemoryTypeDevice) return static_cast<char*>(const_cast<void*>(p));
+  if (attr.type == hipMemoryTypeHost && attr.devicePointer) return static_cast<char*>(attr.devicePointer);
+  return nullptr;
+}
+
 }  // namespace pa
 
 extern "C" int pa_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
@@ -466,6 +512,34 @@ extern "C" int pa_swap_blocks(const void* src, void* dst, const int64_t* block_p
   hipStream_t st = static_cast<hipStream_t>(stream);
   const char* s = static_cast<const char*>(src);
   char* d = static_cast<char*>(dst);
+  // Many scattered blocks: one kernel launch per 256 pairs when both sides can be
+  // addressed by the device and the blocks are whole 16-byte words.
+  static const int kernel_min_pairs = [] {
+    const char* e = getenv("PA_SWAP_KERNEL_MIN_PAIRS");  // tuning aid; 0 = never use the kernel
+    return e ? atoi(e) : 8;
+  }();
+  if (kernel_min_pairs > 0 && num_pairs >= kernel_min_pairs && block_bytes % 16 == 0) {
+    char* ds = device_alias(src);
+    char* dd = device_alias(dst);
+    if (ds && dd && aligned16(ds) && aligned16(dd)) {
+      SwapTable tab;
+      tab.src = ds;
+      tab.dst = dd;
+      int splits = (int)((block_bytes / 16 + 4095) / 4096);  // ~64 KiB per workgroup
+      if (splits < 1) splits = 1;
+      if (splits > 65535) splits = 65535;
+      for (int p0 = 0; p0 < num_pairs; p0 += kCopyMaxPairs) {
+        const int np = num_pairs - p0 < kCopyMaxPairs ? num_pairs - p0 : kCopyMaxPairs;
+        for (int p = 0; p < np; p++) {
+          tab.src_block[p] = block_pairs[2 * (p0 + p)];
+          tab.dst_block[p] = block_pairs[2 * (p0 + p) + 1];
+        }
+        hipLaunchKernelGGL(pa_swap_blocks_kernel, dim3(np, splits), dim3(256), 0, st, tab, block_bytes, splits);
+        PA_CHECK_LAUNCH("pa_swap_blocks kernel launch");
+      }
+      return PA_OK;
+    }
+  }
   // merge runs of consecutive source AND destination blocks into one copy
   int p = 0;
   while (p < num_pairs) {
