@@ -95,7 +95,7 @@ int pa_single_query_cached_kv_attention(
  * stream) the library may split every sequence's context into partitions that
  * run as separate workgroups and are combined by a second kernel; it does so
  * when num_seqs * num_heads alone cannot fill the GPU (small batches), and for
- * big batches whose longest context exceeds 2048 tokens (there, the partitions
+ * big batches whose longest context exceeds 1024 tokens (there, the partitions
  * that exist are listed on the device first, so that one long sequence among
  * short ones does not set the launch time alone).  With
  * workspace == NULL, or one that is too small, it behaves exactly like

@@ -49,6 +49,8 @@ def configs():
     add("ns_outlier_2k_bs64", ragged="outlier", ctx=2048, S=64)
     add("ns_bs64_ctx2048", ctx=2048, S=64)
     add("ns_bs32_ragged2048", ctx=2048, S=32, ragged=True)
+    add("ns_bs64_ragged2048", ctx=2048, S=64, ragged=True)
+    add("ns_bs256_ragged2048", ctx=2048, S=256, ragged=True)
     add("ns_bf16", dt="bf16")
     add("ns_f32", dt="f32", S=128)
     add("c4_llama13b_tp2", H=20)
