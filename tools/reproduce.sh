@@ -1,0 +1,22 @@
+#!/usr/bin/env bash
+# The commands behind the numbers in DESIGN.md, for a box with one MI355X.
+# Each writes its output under gpurun_out/; the copies kept in profiles/ were
+# made from those files.
+set -euo pipefail
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build()"
+python -u bench.py                                  | tee gpurun_out/bench.json            # profiles/r01k_bench.json
+python -u tools/sweep_decode.py --graph             | tee gpurun_out/sweep_decode.log      # profiles/r01g_decode_sweep.txt
+python -u tools/read_bw.py --build && python -u tools/read_bw.py | tee gpurun_out/read_bw.log   # profiles/r01j_hbm_read_ceiling.txt
+python -u tools/bench_cache_ops.py                  | tee gpurun_out/bench_cache.log       # profiles/r01f_cache_ops_bench.txt
+python -u tools/bench_swap.py                       | tee gpurun_out/bench_swap.log
+python -u tools/bench_elementwise.py                | tee gpurun_out/bench_elementwise.log # profiles/r01d_elementwise_bench.txt
+python -u tools/bench_prompt.py                     | tee gpurun_out/bench_prompt.log      # profiles/r01e_prompt_attention_bench.txt
+python -u tools/bench_decoder_step.py               | tee gpurun_out/decoder_step.log      # profiles/r01h_decoder_step.txt
+python -u tools/exp_step.py                         | tee gpurun_out/exp_step.log          # reshape_and_cache -> decode interaction
+# rocprofv3 passes (kernel trace, then FETCH_SIZE and WRITE_SIZE each in a run of its own):
+#   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+#   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
+#   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
+#   python tools/summarize_profiles.py gpurun_out/prof <tag>
