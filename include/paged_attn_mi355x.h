@@ -165,7 +165,7 @@ int pa_copy_blocks(
  * Whole-block copies between two different cache tensors (GPU<->GPU on one
  * device, GPU->pinned host, pinned host->GPU).  Replaces swap_blocks
  * (csrc/cache_kernels.cu:9-47).  block_pairs as in pa_copy_blocks (HOST).
- * Eight or more pairs are moved by one kernel launch per 256 pairs when both
+ * Two or more pairs are moved by one kernel launch per 256 pairs when both
  * sides are addressable by the device (device memory, or pinned host memory,
  * which is mapped): scattered 128 KiB blocks then move at PCIe rate instead of
  * at the rate the host can issue copies.  Otherwise runs of consecutive
