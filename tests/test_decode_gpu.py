@@ -309,3 +309,45 @@ def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype):
         for _ in range(2):  # twice on one workspace: the plan kernel rewinds the counters
             got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=True), dtype)
             helpers.assert_close(got, ref, atol, 2 * rtol, f"item list, announced {announced}")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_decode_randomized_shapes_against_oracle(pkg, seed):
+    """Differential test over random shapes: batch size, head count, head size,
+    block size, dtype, context-length mixture (empty, short, around the
+    1024-token partition edge, long), padded tables, with and without the
+    workspace — so that every launch form (rows, uniform partitions, item list)
+    and both workgroup widths meet odd sizes."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = ["float16", "bfloat16", "float32"][seed % 3]
+    D = int(rng.choice([64, 80, 96, 128]))
+    B = int(rng.choice([8, 16, 32]))
+    H = int(rng.choice([1, 2, 3, 5, 8]))
+    S = int(rng.choice([1, 2, 7, 33, 70, 130, 300]))
+    kinds = rng.choice(5, size=S, p=[0.05, 0.45, 0.2, 0.2, 0.1])
+    ctx = []
+    for k in kinds:
+        if k == 0:
+            ctx.append(0)
+        elif k == 1:
+            ctx.append(int(rng.integers(1, 200)))
+        elif k == 2:
+            ctx.append(int(rng.integers(1000, 1050)))
+        elif k == 3:
+            ctx.append(int(rng.integers(200, 1000)))
+        else:
+            ctx.append(int(rng.integers(1050, 2600)))
+    if S * H * sum(ctx) * D > 4e8:  # keep the oracle fast
+        ctx = [c // 4 for c in ctx]
+    case = datagen.DecodeCase(name=f"fuzz{seed}", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                              num_blocks=sum((c + B - 1) // B for c in ctx) + 3, context_lens=ctx, dist="normal",
+                              tables="permutation", table_pad=int(rng.integers(0, 4)), scale=float(rng.uniform(0.05, 0.2)),
+                              seed=2000 + seed)
+    inp = datagen.make_decode_inputs(case)
+    ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], dtype), dtype)
+    atol, rtol = helpers.TIGHT[dtype]
+    for split in (False, True):
+        got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=split), dtype)
+        helpers.assert_close(got, ref, atol, 2 * rtol, f"seed {seed} S={S} H={H} D={D} B={B} {dtype} split={split}")
