@@ -321,3 +321,36 @@ def test_kernel_with_256_row_workgroups_against_torch(pkg, dtype_name, H, D, len
                                            v[lo:lo + n].transpose(0, 1).float(), is_causal=True, scale=scale)
         assert torch.allclose(out[lo:lo + n].float(), o.transpose(0, 1), atol=tol, rtol=tol), n
         lo += n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_kernel_randomized_shapes_against_oracle(pkg, seed):
+    """Differential test over random prompt batches: number and lengths of
+    prompts, head count, head size, dtype, scale, leading and trailing rows
+    that belong to no prompt (cu_seqlens[0] > 0)."""
+    import torch
+    rng = np.random.default_rng(3000 + seed)
+    dtype = ["float16", "bfloat16", "float32"][seed % 3]
+    D = int(rng.choice([64, 80, 96, 128]))
+    H = int(rng.choice([1, 2, 3, 4]))
+    lens = [int(x) for x in rng.integers(1, 400, size=int(rng.integers(1, 7)))]
+    lead, trail = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+    case = datagen.PromptCase(name=f"fuzz{seed}", dtype=dtype, seq_lens=[lead] + lens, num_heads=H, head_size=D,
+                              dist="normal", pad_tokens=trail, seed=3100 + seed)
+    inp = datagen.make_prompt_inputs(case)
+    cu = inp["cu_seqlens"][1:]  # the first `lead` rows are outside every prompt
+    scale = float(rng.uniform(0.03, 0.3))
+    qkv = inp["qkv"]
+    ref = pa_oracle.multi_query_kv_attention(qkv[lead:, 0], qkv[lead:, 1], qkv[lead:, 2], cu - lead, scale, dtype)
+    t = datagen.storage_to_torch(qkv.copy(), dtype).to(DEV)
+    out = torch.full((qkv.shape[0], H, D), float("nan"), dtype=t.dtype, device=DEV)
+    pkg._capi.multi_query_kv_attention(out, t[:, 0], t[:, 1], t[:, 2], [int(x) for x in cu], scale)
+    torch.cuda.synchronize()
+    n = int(cu[-1])
+    assert bool(torch.isnan(out[:lead].float()).all()) and bool(torch.isnan(out[n:].float()).all())
+    got = datagen.storage_to_float32(datagen.torch_to_storage(out[lead:n], dtype), dtype).astype(np.float64)
+    want = datagen.storage_to_float32(ref, dtype)[: n - lead].astype(np.float64)
+    bound = EPS[dtype] * (2.0 + 3.0 * np.abs(want)) + 2e-6
+    err = np.abs(got - want)
+    assert np.all(err <= bound), f"seed {seed} lens={lens} H={H} D={D} {dtype}: max err {err.max():.3e}"
