@@ -43,7 +43,7 @@ def test_decode_matches_reference_fixture(pkg, name, split):
     inp = datagen.make_decode_inputs(case)
     assert datagen.checksum(inp) == entry["inputs_sha256"]
     got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=split), case.dtype)
-    atol, rtol = helpers.TIGHT[case.dtype]
+    atol, rtol = helpers.decode_atol(inp, case.dtype), helpers.TIGHT[case.dtype][1]
     helpers.assert_close(got, DECODE_DATA[name + "/ref_f32"], atol, rtol, f"{name} vs reference fp32")
     if case.dist == "uniform1e-3":
         want = datagen.storage_to_float32(DECODE_DATA[name + "/ref_dtype"], case.dtype)
@@ -94,7 +94,7 @@ def test_decode_matches_oracle_ragged_batch(pkg, dtype, split):
     ref = pa_oracle.single_query_cached_kv_attention(
         inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
         inp["context_lens"], dtype)
-    atol, rtol = helpers.TIGHT[dtype]
+    atol, rtol = helpers.decode_atol(inp, dtype), helpers.TIGHT[dtype][1]
     helpers.assert_close(got, datagen.storage_to_float32(ref, dtype), atol, 2 * rtol, f"ragged {dtype}")
 
 
@@ -303,7 +303,7 @@ def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype):
     ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
         inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
         inp["context_lens"], dtype), dtype)
-    atol, rtol = helpers.TIGHT[dtype]
+    atol, rtol = helpers.decode_atol(inp, dtype), helpers.TIGHT[dtype][1]
     for announced in (inp["max_context_len"], 3000):
         inp["max_context_len"] = announced
         for _ in range(2):  # twice on one workspace: the plan kernel rewinds the counters
@@ -347,7 +347,46 @@ def test_decode_randomized_shapes_against_oracle(pkg, seed):
     ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
         inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
         inp["context_lens"], dtype), dtype)
-    atol, rtol = helpers.TIGHT[dtype]
+    atol, rtol = helpers.decode_atol(inp, dtype), helpers.TIGHT[dtype][1]
     for split in (False, True):
         got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=split), dtype)
         helpers.assert_close(got, ref, atol, 2 * rtol, f"seed {seed} S={S} H={H} D={D} B={B} {dtype} split={split}")
+
+
+def test_decode_item_list_plan_leaves_near_uniform_batches_unsplit(pkg):
+    """Item-list mode decides on the device whether partitions pay: a batch
+    whose longest context is within a quarter of the mean keeps one workgroup
+    per row (no listed pairs, partition length 'infinite'), a mixed batch on the
+    same workspace right after it is split.  The plan sits in the last three
+    words of the workspace.  Both results must match the oracle."""
+    import torch
+    H, D, B = 8, 64, 16
+    uniform = [1400 + (13 * i) % 120 for i in range(40)]
+    mixed = [3000 if i % 7 == 0 else 150 + i for i in range(40)]
+    nbytes = pkg._capi.decode_workspace_bytes(40, H, D, B, 3000)
+    assert nbytes > 0 and nbytes >= pkg._capi.decode_workspace_bytes(40, H, D, B, max(uniform))
+    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda:0")
+    for name, ctx, split_expected in (("uniform", uniform, False), ("mixed", mixed, True), ("uniform again", uniform, False)):
+        case = datagen.DecodeCase(name="plan", dtype="float16", num_seqs=len(ctx), num_heads=H, head_size=D, block_size=B,
+                                  num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                  tables="permutation", seed=91)
+        inp = datagen.make_decode_inputs(case)
+        qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+        out = torch.full((len(ctx), H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
+        need = pkg._capi.decode_workspace_bytes(len(ctx), H, D, B, inp["max_context_len"])
+        view = ws[:need // 4]
+        pkg._capi.single_query_cached_kv_attention_ws(out, query, kc, vc, inp["scale"], bt, cl, B,
+                                                      inp["max_context_len"], view)
+        torch.cuda.synchronize()
+        plan = view.view(torch.int32)[-3:].tolist()
+        if split_expected:
+            bpp = plan[2]
+            assert bpp * B >= 1024 and bpp < (1 << 24), name
+            assert plan[1] == sum(min((c + bpp * B - 1) // (bpp * B), 4) - 1 for c in ctx), name
+        else:
+            assert plan[1] == 0 and plan[2] == 1 << 24, name
+        ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+            inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+            inp["context_lens"], case.dtype), case.dtype)
+        atol, rtol = helpers.TIGHT[case.dtype]
+        helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, name)

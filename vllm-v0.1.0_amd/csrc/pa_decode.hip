@@ -39,6 +39,10 @@ namespace pa {
 
 // ---- element traits ---------------------------------------------------------
 
+#ifndef PA_DECODE_BF16_DOT2
+#define PA_DECODE_BF16_DOT2 1
+#endif
+
 // Bit casts go through by-value helpers: __builtin_bit_cast applied directly
 // to an element of an ext_vector (v[i]) reads element 0 for every i.
 __device__ __forceinline__ f16x2 as_f16x2(uint32_t w) { return __builtin_bit_cast(f16x2, w); }
@@ -52,10 +56,15 @@ struct ElemF32 {
     for (int i = 0; i < 4; i++) acc = __builtin_fmaf(__uint_as_float(a[i]), __uint_as_float(b[i]), acc);
     return acc;
   }
+  // the probabilities of a lane's X tokens, in the form pv() consumes
+  struct Probs {
+    float p[4];
+  };
+  static __device__ __forceinline__ Probs probs(const float* p) { return Probs{{p[0], p[1], p[2], p[3]}}; }
   // acc + sum_e p[e] * v[e]
-  static __device__ __forceinline__ float pv(const float* p, u32x4 v, float acc) {
+  static __device__ __forceinline__ float pv(const Probs& p, u32x4 v, float acc) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(p[i], __uint_as_float(v[i]), acc);
+    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(p.p[i], __uint_as_float(v[i]), acc);
     return acc;
   }
   static __device__ __forceinline__ u32x4 mask(u32x4 v, int first_invalid) {
@@ -76,12 +85,18 @@ struct ElemF16 {
       acc = __builtin_amdgcn_fdot2(as_f16x2(a[i]), as_f16x2(b[i]), acc, false);
     return acc;
   }
-  static __device__ __forceinline__ float pv(const float* p, u32x4 v, float acc) {
+  struct Probs {
+    float p[8];
+  };
+  static __device__ __forceinline__ Probs probs(const float* p) {
+    return Probs{{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]}};
+  }
+  static __device__ __forceinline__ float pv(const Probs& p, u32x4 v, float acc) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const f16x2 h = as_f16x2(v[i]);
-      acc = __builtin_fmaf(p[2 * i], (float)h[0], acc);
-      acc = __builtin_fmaf(p[2 * i + 1], (float)h[1], acc);
+      acc = __builtin_fmaf(p.p[2 * i], (float)h[0], acc);  // v_fma_mix_f32: no separate conversion
+      acc = __builtin_fmaf(p.p[2 * i + 1], (float)h[1], acc);
     }
     return acc;
   }
@@ -106,14 +121,46 @@ struct ElemBF16 {
       acc = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(a[i]), as_bf16x2(b[i]), acc, false);
     return acc;
   }
-  static __device__ __forceinline__ float pv(const float* p, u32x4 v, float acc) {
+#if PA_DECODE_BF16_DOT2
+  // bfloat16 has no mixed-precision FMA: widening each value costs an
+  // instruction of its own.  Instead the probabilities are rounded to bfloat16
+  // once per block (as the reference rounds them to the storage type,
+  // csrc/attention/attention_kernels.cu:236-254) and each pair of tokens is one
+  // v_dot2_f32_bf16 with fp32 accumulation.
+  struct Probs {
+    uint32_t w[4];
+  };
+  static __device__ __forceinline__ Probs probs(const float* p) {
+    Probs r;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      acc = __builtin_fmaf(p[2 * i], __uint_as_float(v[i] << 16), acc);
-      acc = __builtin_fmaf(p[2 * i + 1], __uint_as_float(v[i] & 0xffff0000u), acc);
+      const bf16x2 h = {(__bf16)p[2 * i], (__bf16)p[2 * i + 1]};
+      r.w[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return r;
+  }
+  static __device__ __forceinline__ float pv(const Probs& p, u32x4 v, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      acc = __builtin_amdgcn_fdot2_f32_bf16(as_bf16x2(p.w[i]), as_bf16x2(v[i]), acc, false);
+    return acc;
+  }
+#else
+  struct Probs {
+    float p[8];
+  };
+  static __device__ __forceinline__ Probs probs(const float* p) {
+    return Probs{{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]}};
+  }
+  static __device__ __forceinline__ float pv(const Probs& p, u32x4 v, float acc) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc = __builtin_fmaf(p.p[2 * i], __uint_as_float(v[i] << 16), acc);
+      acc = __builtin_fmaf(p.p[2 * i + 1], __uint_as_float(v[i] & 0xffff0000u), acc);
     }
     return acc;
   }
+#endif
   static __device__ __forceinline__ u32x4 mask(u32x4 v, int first_invalid) { return ElemF16::mask(v, first_invalid); }
   static __device__ __forceinline__ storage from_float(float f) { return (__bf16)f; }
   static __device__ __forceinline__ float to_float(storage s) { return (float)s; }
@@ -174,7 +221,7 @@ struct DecodeArgs {
   int blocks_per_part;
   int group;  // sequences per work-order group (see the kernel)
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
-  unsigned* counters;     // kModeList: [1] number of pairs ([0] unused)
+  unsigned* counters;     // kModeList: [1] number of pairs, [2] blocks per partition in force ([0] unused)
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
 };
 
@@ -291,11 +338,12 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   const int ctx = a.context_lens[seq];
   const int nblk_seq = (ctx + B - 1) / B;
   // kModeList: a sequence that fits one partition is finished here, without the workspace
-  const bool direct = !PART || (MODE == kModeList && nblk_seq <= a.blocks_per_part);
-  const int blk_begin = PART ? part * a.blocks_per_part : 0;
+  const int bpp = MODE == kModeList ? (int)a.counters[2] : a.blocks_per_part;  // the plan kernel's decision
+  const bool direct = !PART || (MODE == kModeList && nblk_seq <= bpp);
+  const int blk_begin = PART ? part * bpp : 0;
   // the last partition runs to the end of the context even if the context is
   // longer than the max_context_len the partition plan was made for
-  const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + a.blocks_per_part) : nblk_seq;
+  const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + bpp) : nblk_seq;
   if (MODE == kModeParts && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
   const int* __restrict__ table = a.block_tables + (int64_t)seq * a.max_blocks_per_seq;
   // Neighbouring sequences' tables, to spot shared physical blocks (forked
@@ -461,8 +509,9 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 #pragma unroll
       for (int i = 0; i < NV; i++) tl.v[i] = E::mask(tl.v[i], first_invalid);
     }
+    const typename E::Probs probs = E::probs(pvv);
 #pragma unroll
-    for (int i = 0; i < NV; i++) acc[i] = E::pv(pvv, tl.v[i], acc[i] * alpha);
+    for (int i = 0; i < NV; i++) acc[i] = E::pv(probs, tl.v[i], acc[i] * alpha);
   };
 
   // Two register tiles, alternating: the loads of block n+1 are issued before
@@ -539,25 +588,56 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   }
 }
 
-// Lists the (sequence, partition >= 1) pairs of a batch for kModeList: one
-// workgroup scans context_lens 256 sequences at a time.  A sequence has
-// ceil(blocks / blocks_per_part) partitions, at most max_parts (the last
-// partition then runs to the end of the context).
+// Plans kModeList for one batch, from context_lens: one workgroup.
+//
+// First the decision whether to split at all.  Partitions exist to keep one
+// long sequence from setting the launch time alone; when the longest sequence
+// is within uniform_pct percent of the mean, rows end together anyway and the
+// second workgroup per row, the workspace round trip and the merge only cost
+// (3-4 % at 256 sequences of exactly 2048 or 4096 tokens).  The partition
+// length in force goes to counters[2] for the decode and merge kernels: the
+// planned one, or kNoSplitBlocks.
+//
+// Then the list of (sequence, partition >= 1) pairs, 256 sequences at a time.
+// A sequence has ceil(blocks / blocks_per_part) partitions, at most max_parts
+// (the last partition then runs to the end of the context).
+constexpr int kNoSplitBlocks = 1 << 24;
+
 __global__ void __launch_bounds__(256)
 pa_decode_plan_kernel(const int* __restrict__ context_lens, const int num_seqs, const int block_size,
-                      const int blocks_per_part, const int max_parts, uint32_t* __restrict__ items,
-                      unsigned* __restrict__ counters) {
+                      const int blocks_per_part, const int max_parts, const int uniform_pct,
+                      uint32_t* __restrict__ items, unsigned* __restrict__ counters) {
   __shared__ unsigned scan[256];
+  __shared__ unsigned long long sums[256];
   __shared__ unsigned base;
   const int tid = threadIdx.x;
+  unsigned long long total = 0;
+  unsigned longest = 0;
+  for (int seq = tid; seq < num_seqs; seq += 256) {
+    const unsigned nblk = (unsigned)((max(context_lens[seq], 0) + block_size - 1) / block_size);
+    total += nblk;
+    longest = max(longest, nblk);
+  }
+  sums[tid] = total;
+  scan[tid] = longest;
   if (tid == 0) base = 0;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) {
+      sums[tid] += sums[tid + off];
+      scan[tid] = max(scan[tid], scan[tid + off]);
+    }
+    __syncthreads();
+  }
+  const bool uniform = (unsigned long long)scan[0] * 100ull * (unsigned)num_seqs <= sums[0] * (unsigned long long)uniform_pct;
+  const int bpp = uniform ? kNoSplitBlocks : blocks_per_part;
   __syncthreads();
   for (int s0 = 0; s0 < num_seqs; s0 += 256) {
     const int seq = s0 + tid;
     unsigned extra = 0;
     if (seq < num_seqs) {
-      const int nblk = (context_lens[seq] + block_size - 1) / block_size;
-      extra = (unsigned)(min(max((nblk + blocks_per_part - 1) / blocks_per_part, 1), max_parts) - 1);
+      const int nblk = (max(context_lens[seq], 0) + block_size - 1) / block_size;
+      extra = (unsigned)(min(max((nblk + bpp - 1) / bpp, 1), max_parts) - 1);
     }
     scan[tid] = extra;
     __syncthreads();
@@ -576,6 +656,7 @@ pa_decode_plan_kernel(const int* __restrict__ context_lens, const int num_seqs, 
   if (tid == 0) {
     counters[0] = 0u;
     counters[1] = base;
+    counters[2] = (unsigned)bpp;
   }
 }
 
@@ -585,13 +666,16 @@ pa_decode_plan_kernel(const int* __restrict__ context_lens, const int num_seqs, 
 // a group of partitions issued before the first use.
 template <typename E, int D>
 __global__ void __launch_bounds__(64)
-pa_decode_merge_kernel(const DecodeArgs a, const int tokens_per_part, const int skip_single) {
+pa_decode_merge_kernel(const DecodeArgs a, const int planned_tokens_per_part, const int block_size,
+                       const int skip_single) {
   typedef typename E::storage T;
   constexpr int PER = (D + 63) / 64;
   const int lane = threadIdx.x;
   const int64_t row = blockIdx.x;  // seq * num_heads + head
   const int seq = (int)(row / a.num_heads);
   const int ctx = a.context_lens[seq];
+  // kModeList (skip_single): the partition length is the plan kernel's
+  const int tokens_per_part = skip_single ? (int)a.counters[2] * block_size : planned_tokens_per_part;
   const int nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
   if (skip_single && nparts <= 1) return;  // kModeList wrote this row directly
   const float* __restrict__ ml = a.ws_ml + 2 * row * a.num_parts;
@@ -647,6 +731,7 @@ pa_decode_merge_kernel(const DecodeArgs a, const int tokens_per_part, const int 
 // ---- host side ----------------------------------------------------------------
 
 constexpr int kNumWaves = 4;
+constexpr int kListUniformPct = 125;  // kModeList: no partitions while the longest context <= 1.25 x the mean
 
 // Waves per workgroup: 4, except head size 64, whose rows stream a quarter of
 // the bytes of a head-size-128 row against the same fixed cost and whose 91
@@ -671,16 +756,20 @@ static int launch(const DecodeArgs& a, int tokens_per_part, hipStream_t stream) 
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeParts>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64),
                        0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (partitioned) launch");
-    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, 0);
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 0);
     PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   } else {
+    static const int uniform_pct = [] {
+      const char* e = getenv("PA_DECODE_LIST_UNIFORM_PCT");  // tuning aid only: 0 = always split
+      return e ? atoi(e) : kListUniformPct;
+    }();
     hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(256), 0, stream, a.context_lens, a.num_seqs, B,
-                       a.blocks_per_part, a.num_parts, const_cast<uint32_t*>(a.items), a.counters);
+                       a.blocks_per_part, a.num_parts, uniform_pct, const_cast<uint32_t*>(a.items), a.counters);
     PA_CHECK_LAUNCH("pa_decode_plan_kernel launch");
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeList>), dim3(a.list_slots + rows), dim3(NW * 64), 0, stream,
                        a);
     PA_CHECK_LAUNCH("pa_decode_kernel (item list) launch");
-    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, 1);
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 1);
     PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   }
   return PA_OK;
@@ -767,10 +856,10 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
 
 // Workspace: accumulators [rows * parts][D], then (max, sum) pairs
 // [rows * parts][2], fp32; kModeList appends the item list [num_seqs * parts]
-// and the two counters.
+// and the three counters.
 static size_t workspace_bytes_for(int64_t rows, int num_parts, int head_size, int64_t list_seqs) {
   size_t n = (size_t)rows * num_parts * (head_size + 2) * sizeof(float);
-  if (list_seqs > 0) n += (size_t)list_seqs * num_parts * sizeof(uint32_t) + 2 * sizeof(unsigned);
+  if (list_seqs > 0) n += (size_t)list_seqs * num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
   return n;
 }
 
