@@ -150,3 +150,24 @@ def test_small_llama_greedy_generation_matches_dense_recompute(pkg):
         check_and_extend([logits[r] for r in range(len(ids))], ids)
         if step == 6:  # the fork sees exactly what its parent sees
             assert torch.equal(logits[ids.index(1)], logits[ids.index(3)])
+
+
+def test_throughput_harness_serves_every_request_on_a_tiny_model(pkg):
+    """tools/bench_throughput.py (the reference's offline-throughput benchmark
+    restated): continuous batching of mixed prompt + generation steps through
+    the paged path.  On a tiny model with a tight token budget and few cache
+    blocks: every request gets exactly its output length, and all blocks come
+    back."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_throughput.py")
+    spec = importlib.util.spec_from_file_location("bench_throughput", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(model="tiny", num_prompts=40, seed=3, max_num_batched_tokens=1100, max_num_seqs=12,
+                  num_blocks=12 * 128 + 64, verbose=False)
+    reqs = mod.sample_requests(40, 3)
+    assert res["output_tokens"] == sum(o for _, o in reqs) and res["prompt_tokens"] == sum(p for p, _ in reqs)
+    assert res["steps"] >= max(o for _, o in reqs)
+    assert 0 < res["steps_with_prompts"] <= 40
+    assert res["output_tokens_per_s"] > 0
