@@ -7,10 +7,12 @@ Metric (BASELINE.json): output tokens/s + paged-attention HBM GB/s, LLaMA-7B
 TP=1, batch 256.  One STEP is one decode iteration of the hot path over the
 whole model: for each of the 32 layers, `cache_ops.reshape_and_cache` writes
 the batch's new K/V vectors into that layer's paged cache and
-`attention_ops.single_query_cached_kv_attention` attends over it (batch 256,
-32 heads x 128, block 16, context 1024, fp16; every logical block a distinct
-physical block; one 2 GiB K and one 2 GiB V cache per layer, all resident in
-HBM before timing starts).  value = tokens produced per second by that path =
+`attention_ops.single_query_cached_kv_attention_planned` attends over it
+(batch 256, 32 heads x 128, block 16, context 1024, fp16; every logical block a
+distinct physical block; one 2 GiB K and one 2 GiB V cache per layer, all
+resident in HBM before timing starts).  The attention's launch plan (the order
+in which rows are dealt to the XCDs) depends on the context lengths only and is
+made once per step, by layer 0, as in this package's PagedAttention layer.  value = tokens produced per second by that path =
 batch * steps / elapsed.  The GEMMs, sampler and scheduler of the full model
 are outside this path and are not run.
 
@@ -249,11 +251,18 @@ def main(argv=None):
     slot_mapping = (block_tables[:, pos // B].to(torch.int64) * B + pos % B).to(torch.int32)
     scale = 1.0 / D ** 0.5
 
+    # The layers of a step share context_lens, hence the launch plan that depends on them
+    # alone: layer 0 makes it into the step's workspace, the others reuse it (what
+    # PagedAttention.forward of this package does through the step's InputMetadata).
+    ws_bytes = attention_ops.decode_workspace_bytes(S, H, D, B, CTX)
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+
     def step():
         for l in range(L):
             cache_ops.reshape_and_cache(key, value, key_caches[l], value_caches[l], slot_mapping)
-            attention_ops.single_query_cached_kv_attention(
-                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX)
+            attention_ops.single_query_cached_kv_attention_planned(
+                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
+                workspace, l > 0)
 
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     units = dist.sum_float(float(S * args.steps), device)
@@ -268,8 +277,9 @@ def main(argv=None):
         for i, (e0, e1) in enumerate(evs):
             l = i % L
             e0.record()
-            attention_ops.single_query_cached_kv_attention(
-                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX)
+            attention_ops.single_query_cached_kv_attention_planned(
+                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
+                workspace, True)  # the plan of the timed steps above is still in the workspace
             e1.record()
         torch.cuda.synchronize()
         times_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)

@@ -90,7 +90,7 @@ int pa_single_query_cached_kv_attention(
 
 /*
  * Same operation with a caller-provided scratch buffer.  With a workspace of
- * at least pa_decode_workspace_bytes(...) bytes (device memory, 4-byte
+ * at least pa_decode_workspace_bytes(...) bytes (device memory, 8-byte
  * aligned, contents irrelevant, may be reused by the next call on the same
  * stream) the library may split every sequence's context into partitions that
  * run as separate workgroups and are combined by a second kernel; it does so
@@ -103,7 +103,8 @@ int pa_single_query_cached_kv_attention(
  * up to fp32 summation order.  No counterpart in the reference, whose kernel
  * always runs one thread block per (sequence, head) (:367).
  *
- * pa_decode_workspace_bytes returns 0 when the library would not split.
+ * pa_decode_workspace_bytes returns 0 when the library has no use for a
+ * workspace.
  */
 size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size,
                                  int block_size, int max_context_len);
@@ -114,6 +115,31 @@ int pa_single_query_cached_kv_attention_ws(
     int num_seqs, int num_heads, int head_size, int block_size,
     int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
     int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Same again, for callers that run the operation several times on the same
+ * context_lens — every layer of a decode step does.  The head of the
+ * workspace holds a plan that depends on context_lens only: for batches of 64
+ * to 1024 sequences the order in which the (sequence, head) rows are dealt to
+ * the GPU's eight XCDs (sequences placed by length, so that the XCDs finish
+ * together: worth 4 % on a batch of random lengths, 13 % on long-tailed
+ * lengths), and for big batches with long contexts the list of partitions.
+ * The first call of a step passes plan_ready = 0 and makes the plan; the
+ * others pass plan_ready = 1 with the SAME workspace, num_seqs, num_heads,
+ * head_size, block_size, max_context_len and an unchanged context_lens, and
+ * skip that kernel.  The rest of the workspace is scratch as above.  A plan
+ * that was never made, or made for other arguments, gives wrong results (but
+ * no out-of-range access).  pa_single_query_cached_kv_attention_ws makes the
+ * plan on every call, and makes the row order only for launches big enough to
+ * win it back.  No counterpart in the reference.
+ */
+int pa_single_query_cached_kv_attention_planned(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    float scale, const int32_t* block_tables, const int32_t* context_lens,
+    int num_seqs, int num_heads, int head_size, int block_size,
+    int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
+    int dtype, void* workspace, size_t workspace_bytes, int plan_ready,
+    void* stream);
 
 /*
  * Scatter new key/value vectors into the paged caches.

@@ -13,8 +13,10 @@ DECODE_META, DECODE_DATA = helpers.load_decode_golden()
 
 def _run_capi(pkg, inp, case, device="cuda:0", split=False):
     """split=False: pa_single_query_cached_kv_attention (one workgroup per
-    row).  split=True: the _ws entry point with the workspace it asks for, so
-    small batches take the partitioned kernel + merge kernel."""
+    row).  split=True: the _planned entry point (plan made by this call) with
+    the workspace it asks for, so small batches take the partitioned kernel +
+    merge kernel, big ones with long contexts the item list, and batches of 16
+    units of sequences and more the balanced row order."""
     import torch
     qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, device)
     out = torch.full((case.num_seqs, case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=device)
@@ -22,9 +24,9 @@ def _run_capi(pkg, inp, case, device="cuda:0", split=False):
         nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size,
                                                   case.block_size, inp["max_context_len"])
         ws = torch.full((max(nbytes, 4) // 4,), float("nan"), dtype=torch.float32, device=device)
-        pkg._capi.single_query_cached_kv_attention_ws(
+        pkg._capi.single_query_cached_kv_attention_planned(
             out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"],
-            ws if nbytes else None)
+            ws if nbytes else None, False)
     else:
         pkg._capi.single_query_cached_kv_attention(
             out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"])
@@ -52,8 +54,11 @@ def test_decode_matches_reference_fixture(pkg, name, split):
 
 def test_partition_plan_splits_small_batches_only(pkg):
     c = pkg._capi
-    # 256 x 32 rows fill the chip on their own: no workspace wanted
-    assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == 0
+    # 256 x 32 rows fill the chip on their own: no partitions, only the row table of the
+    # balanced order (8 XCDs x 32 sequences x 8 bytes)
+    assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == 8 * 32 * 8
+    # too few sequences to balance, contexts too short to split
+    assert c.decode_workspace_bytes(40, 32, 128, 16, 1024) == 0
     # one sequence: 32 rows -> split into partitions of at least 64 tokens / 4 blocks
     n = c.decode_workspace_bytes(1, 32, 128, 16, 1024)
     assert n > 0 and n % ((128 + 2) * 4 * 32) == 0
@@ -261,39 +266,49 @@ def test_decode_north_star_size_properties(pkg):
 
 @pytest.mark.parametrize("num_heads", [1, 8, 32])
 def test_decode_work_order_covers_every_row_for_any_batch_size(pkg, num_heads):
-    """The kernel walks (sequence, head) rows in a permuted order (groups of
-    sequences dealt round-robin to the XCDs, a partial group last).  Batch
-    sizes on both sides of the group size and of 8 groups, with context
-    lengths sorted in descending order: every row must be written, and match
-    the oracle."""
+    """The kernel walks (sequence, head) rows in a permuted order: by batch
+    position (groups of sequences dealt round-robin to the XCDs, a partial
+    group last), or, given a workspace, by the plan kernel's row table
+    (sequences placed by length).  Batch sizes on both sides of the group
+    size, of 8 groups, of 16 units and of the 1024-sequence limit, context
+    lengths sorted: every row must be written, and match the oracle."""
     import torch
     G = max(1, min(16, 128 // num_heads))
-    sizes = sorted({1, G - 1, G, G + 1, 7 * G, 8 * G - 1, 8 * G, 8 * G + 1, 9 * G + 3, 17 * G} - {0})
+    U = min(G, 4)
+    sizes = sorted({1, G - 1, G, G + 1, 7 * G, 8 * G - 1, 8 * G, 8 * G + 1, 9 * G + 3, 17 * G,
+                    15 * U + 1, 16 * U, 16 * U + 1, 24 * U + 2, 257, 1024, 1025} - {0})
     for S in sizes:
+        if S * num_heads > 12000:
+            continue  # keeps the oracle fast; the 32-head case stops at 257 sequences
         ctx = sorted((1 + (37 * i) % 90 for i in range(S)), reverse=True)
+        if S % 2:
+            ctx = ctx[::-1]
         case = datagen.DecodeCase(name=f"order{S}", dtype="float16", num_seqs=S, num_heads=num_heads, head_size=64,
                                   block_size=16, num_blocks=6 * S + 8, context_lens=ctx, dist="normal",
                                   tables="permutation", seed=300 + S)
         inp = datagen.make_decode_inputs(case)
-        out = _run_capi(pkg, inp, case)
-        assert not bool(torch.isnan(out.float()).any()), f"S={S}: rows left unwritten"
-        ref = pa_oracle.single_query_cached_kv_attention(
+        ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
             inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
-            inp["context_lens"], case.dtype)
-        helpers.assert_close(helpers.out_to_f32(out, case.dtype), datagen.storage_to_float32(ref, case.dtype),
-                             2e-5, 1e-3, f"S={S} H={num_heads}")
+            inp["context_lens"], case.dtype), case.dtype)
+        # without a workspace: batch order; with one: from 16 units of sequences on, up to 1024
+        # sequences, the order of the plan kernel's row table
+        for split in (False, True):
+            out = _run_capi(pkg, inp, case, split=split)
+            assert not bool(torch.isnan(out.float()).any()), f"S={S} split={split}: rows left unwritten"
+            helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, 2e-5, 1e-3, f"S={S} H={num_heads} split={split}")
 
 
+@pytest.mark.parametrize("reps", [4, 6], ids=["batch_order", "balanced_order"])
 @pytest.mark.parametrize("dtype", ["float16", "float32"])
-def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype):
+def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype, reps):
     """More than 256 rows and a longest context beyond 2048 tokens: the library
     lists the non-empty (sequence, partition) pairs on the device and a
     fixed-size grid draws from the list.  Mixed lengths on both sides of the
     1024-token partition edge, empty contexts, one long outlier; also with an
     understated max_context_len (the last partition must run to the end)."""
     import torch
-    ctx = [5000, 100, 2049, 1024, 1025, 0, 1, 16, 2048, 3000, 1023, 77] * 4 + [4097]
-    S, H, D, B = len(ctx), 8, 64, 16
+    ctx = [5000, 100, 2049, 1024, 1025, 0, 1, 16, 2048, 3000, 1023, 77] * reps + [4097]
+    S, H, D, B = len(ctx), 8, 64, 16  # 16 units of 4 sequences and more take the balanced order
     case = datagen.DecodeCase(name="list", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
                               num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
                               tables="permutation", seed=77)
@@ -390,3 +405,41 @@ def test_decode_item_list_plan_leaves_near_uniform_batches_unsplit(pkg):
             inp["context_lens"], case.dtype), case.dtype)
         atol, rtol = helpers.TIGHT[case.dtype]
         helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, name)
+
+
+@pytest.mark.parametrize("longest", [300, 2600], ids=["rows", "item_list"])
+@pytest.mark.parametrize("entry", ["planned", "ws", "module"])
+def test_decode_plan_shared_by_several_calls(pkg, longest, entry):
+    """One workspace, one plan, several calls with different queries and caches
+    (the layers of a step): plan_ready False, then True.  The workspace starts
+    out as NaN bytes.  Also the per-call forms (_ws entry point, attention_ops
+    module) on the same inputs."""
+    import torch
+    rng = np.random.default_rng(5)
+    S, H, D, B = 100, 8, 64, 16
+    ctx = [int(c) for c in rng.integers(1, longest + 1, size=S)]
+    ctx[17] = 0
+    ctx[3] = longest
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
+    assert nbytes > 0
+    ws = torch.full((nbytes // 4 + 1,), float("nan"), dtype=torch.float32, device="cuda:0")
+    for layer in range(3):
+        case = datagen.DecodeCase(name="shared", dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                                  num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                  tables="permutation", seed=500 + layer)
+        inp = datagen.make_decode_inputs(case)
+        qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+        out = torch.full((S, H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
+        if entry == "planned":
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest, ws,
+                                                               layer > 0)
+        elif entry == "ws":
+            pkg._capi.single_query_cached_kv_attention_ws(out, query, kc, vc, inp["scale"], bt, cl, B, longest, ws)
+        else:
+            pkg.attention_ops.single_query_cached_kv_attention(out, query, kc, vc, inp["scale"], bt, cl, B, longest)
+        torch.cuda.synchronize()
+        ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+            inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+            inp["context_lens"], case.dtype), case.dtype)
+        atol, rtol = helpers.TIGHT[case.dtype]
+        helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"{entry} layer {layer}")

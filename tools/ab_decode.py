@@ -38,6 +38,8 @@ SHAPES = {
     # groups of 3 sequences share the physical blocks of the first half of the context
     "share3": dict(S=256, H=16, D=96, B=16, ctx=1024, ragged=False, share=3),
     "share3_ns": dict(S=255, H=32, D=128, B=16, ctx=1024, ragged=False, share=3),
+    "ragged2048": dict(S=256, H=32, D=128, B=16, ctx=2048, ragged=True),
+    "ragged4096_bs128": dict(S=128, H=32, D=128, B=16, ctx=4096, ragged=True),
 }
 
 
@@ -48,6 +50,12 @@ def load(name):
     lib.pa_single_query_cached_kv_attention.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp]
     lib.pa_single_query_cached_kv_attention.restype = i32
     lib.pa_last_error.restype = ctypes.c_char_p
+    if hasattr(lib, "pa_single_query_cached_kv_attention_planned"):
+        lib.pa_single_query_cached_kv_attention_planned.argtypes = [
+            vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, vp]
+        lib.pa_single_query_cached_kv_attention_planned.restype = i32
+        lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+        lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
     return lib
 
 
@@ -58,6 +66,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--per-round", type=int, default=5)
     ap.add_argument("--sequential", action="store_true")
+    ap.add_argument("--planned", action="store_true",
+                    help="the _planned entry point with its workspace; the plan is made once, outside the timing")
     args = ap.parse_args()
     names = args.libs.split(",")
     libs = {n: load(n) for n in names}
@@ -92,7 +102,25 @@ def main():
         out = torch.empty(S, H, D, dtype=torch.float16, device=dev)
         nbytes = algorithmic_bytes(ctxs, H, D, B, 2)
 
+        wss = {}
+        if args.planned:
+            for n in names:
+                nb = libs[n].pa_decode_workspace_bytes(S, H, D, B, ctx)
+                wss[n] = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+                rc = libs[n].pa_single_query_cached_kv_attention_planned(
+                    out.data_ptr(), q.data_ptr(), kcs[0].data_ptr(), vcs[0].data_ptr(), 1.0 / D ** 0.5, bt.data_ptr(),
+                    cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1, wss[n].data_ptr(), nb, 0, stream)
+                assert rc == 0, libs[n].pa_last_error()
+
         def call(lib, i):
+            if args.planned:
+                n = [k_ for k_, v_ in libs.items() if v_ is lib][0]
+                rc = lib.pa_single_query_cached_kv_attention_planned(
+                    out.data_ptr(), q.data_ptr(), kcs[i % copies].data_ptr(), vcs[i % copies].data_ptr(),
+                    1.0 / D ** 0.5, bt.data_ptr(), cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1,
+                    wss[n].data_ptr(), wss[n].numel(), 1, stream)
+                assert rc == 0, lib.pa_last_error()
+                return
             rc = lib.pa_single_query_cached_kv_attention(
                 out.data_ptr(), q.data_ptr(), kcs[i % copies].data_ptr(), vcs[i % copies].data_ptr(),
                 1.0 / D ** 0.5, bt.data_ptr(), cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1, stream)

@@ -19,6 +19,7 @@ import __graft_entry__  # noqa: E402
 from bench import algorithmic_bytes  # noqa: E402
 
 USE_GRAPH = False
+PLANNED = False  # one launch plan for all timed calls (the layers of a step), not one per call
 SEQUENTIAL = False  # physical block i = logical block i (best case for DRAM page locality)
 DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
 
@@ -45,6 +46,9 @@ def configs():
         add(f"ns_head{D}", D=D)
     add("ns_ragged", ragged=True)
     add("ns_ragged_sorted", ragged="sorted")
+    add("ns_ragged_lognormal", ragged="lognormal", ctx=2048)
+    add("ns_ragged_lognormal_bs128", ragged="lognormal", ctx=2048, S=128)
+    add("ns_ragged_lognormal_1k", ragged="lognormal", ctx=1024)
     add("ns_outlier_8k", ragged="outlier", ctx=8192)
     add("ns_outlier_2k_bs64", ragged="outlier", ctx=2048, S=64)
     add("ns_bs64_ctx2048", ctx=2048, S=64)
@@ -77,6 +81,9 @@ def run(cfg, pkg, device, launches=30):
         ctxs = torch.randint(1, ctx + 1, (S,), generator=g).tolist()
         if cfg["ragged"] == "sorted":
             ctxs.sort(reverse=True)
+        elif cfg["ragged"] == "lognormal":  # long-tailed, like the lengths of a chat corpus
+            rs = __import__("numpy").random.default_rng(0)
+            ctxs = [int(min(max(v, 1), ctx)) for v in rs.lognormal(__import__("math").log(300.0), 1.0, S)]
         elif cfg["ragged"] == "outlier":   # one long sequence among short ones
             ctxs = [ctx // 32] * S
             ctxs[S // 2] = ctx
@@ -111,6 +118,13 @@ def run(cfg, pkg, device, launches=30):
     out = torch.empty(S, H, D, dtype=dt, device=device)
     scale = 1.0 / D ** 0.5
     op = pkg.attention_ops.single_query_cached_kv_attention
+    if PLANNED:
+        ws = torch.empty(pkg.attention_ops.decode_workspace_bytes(S, H, D, B, ctx), dtype=torch.uint8, device=device)
+        planned = pkg.attention_ops.single_query_cached_kv_attention_planned
+        planned(out, q, kcs[0], vcs[0], scale, bt, cl, B, ctx, ws, False)
+
+        def op(out, q, kc, vc, scale, bt, cl, B, ctx):  # noqa: F811
+            planned(out, q, kc, vc, scale, bt, cl, B, ctx, ws, True)
     for i in range(3):
         op(out, q, kcs[i % copies], vcs[i % copies], scale, bt, cl, B, ctx)
     torch.cuda.synchronize()
@@ -162,8 +176,10 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--sequential", action="store_true")
+    ap.add_argument("--planned", action="store_true")
     args = ap.parse_args()
-    global USE_GRAPH, SEQUENTIAL
+    global USE_GRAPH, SEQUENTIAL, PLANNED
+    PLANNED = args.planned
     USE_GRAPH = args.graph
     SEQUENTIAL = args.sequential
     pkg = __graft_entry__.load_package()

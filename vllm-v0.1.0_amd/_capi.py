@@ -29,6 +29,7 @@ EXPORTS = (
     "pa_last_error",
     "pa_single_query_cached_kv_attention",
     "pa_single_query_cached_kv_attention_ws",
+    "pa_single_query_cached_kv_attention_planned",
     "pa_decode_workspace_bytes",
     "pa_multi_query_kv_attention",
     "pa_reshape_and_cache",
@@ -67,6 +68,9 @@ def _load() -> ctypes.CDLL:
     lib.pa_single_query_cached_kv_attention_ws.argtypes = [
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, vp]
     lib.pa_single_query_cached_kv_attention_ws.restype = i32
+    lib.pa_single_query_cached_kv_attention_planned.argtypes = [
+        vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, vp]
+    lib.pa_single_query_cached_kv_attention_planned.restype = i32
     lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
     lib.pa_multi_query_kv_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i64, i64, i64, i32, vp]
@@ -147,6 +151,21 @@ def single_query_cached_kv_attention_ws(out, query, key_cache, value_cache, scal
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
         max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
         _stream_handle(stream))
+    check(rc)
+
+
+def single_query_cached_kv_attention_planned(out, query, key_cache, value_cache, scale, block_tables,
+                                             context_lens, block_size, max_context_len, workspace,
+                                             plan_ready, stream=None) -> None:
+    """One workspace for all calls on the same context_lens: plan_ready False on the first, True after."""
+    S, H, D = query.shape
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    rc = lib.pa_single_query_cached_kv_attention_planned(
+        out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), float(scale),
+        block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
+        max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
+        1 if plan_ready else 0, _stream_handle(stream))
     check(rc)
 
 

@@ -5,17 +5,14 @@
 
 namespace {
 
-void single_query_cached_kv_attention(
-    torch::Tensor& out,           // [num_seqs, num_heads, head_size]
-    torch::Tensor& query,         // [num_seqs, num_heads, head_size]
-    torch::Tensor& key_cache,     // [num_blocks, num_heads, head_size/x, block_size, x]
-    torch::Tensor& value_cache,   // [num_blocks, num_heads, head_size, block_size]
-    float scale,
-    torch::Tensor& block_tables,  // [num_seqs, max_num_blocks_per_seq]
-    torch::Tensor& context_lens,  // [num_seqs]
-    int block_size, int max_context_len) {
+struct DecodeShape {
+  int num_seqs, num_heads, head_size, dtype;
+};
+
+DecodeShape check_decode_args(const char* what, torch::Tensor& out, torch::Tensor& query, torch::Tensor& key_cache,
+                              torch::Tensor& value_cache, torch::Tensor& block_tables, torch::Tensor& context_lens,
+                              int block_size) {
   using namespace pa_shim;
-  const char* what = "single_query_cached_kv_attention";
   TORCH_CHECK(query.is_cuda() && out.is_cuda() && key_cache.is_cuda() && value_cache.is_cuda() &&
                   block_tables.is_cuda() && context_lens.is_cuda(),
               what, ": all tensors must be on the GPU");
@@ -39,21 +36,65 @@ void single_query_cached_kv_attention(
               what, ": value_cache shape does not match [num_blocks, ", num_heads, ", ", head_size, ", ", block_size, "]");
   TORCH_CHECK(key_cache.numel() == value_cache.numel() && key_cache.size(3) == block_size, what,
               ": key_cache shape does not match value_cache");
-  // Small batches are split over more workgroups; the scratch for that comes
+  return DecodeShape{num_seqs, num_heads, head_size, dtype};
+}
+
+void single_query_cached_kv_attention(
+    torch::Tensor& out,           // [num_seqs, num_heads, head_size]
+    torch::Tensor& query,         // [num_seqs, num_heads, head_size]
+    torch::Tensor& key_cache,     // [num_blocks, num_heads, head_size/x, block_size, x]
+    torch::Tensor& value_cache,   // [num_blocks, num_heads, head_size, block_size]
+    float scale,
+    torch::Tensor& block_tables,  // [num_seqs, max_num_blocks_per_seq]
+    torch::Tensor& context_lens,  // [num_seqs]
+    int block_size, int max_context_len) {
+  using namespace pa_shim;
+  const char* what = "single_query_cached_kv_attention";
+  const DecodeShape sh = check_decode_args(what, out, query, key_cache, value_cache, block_tables, context_lens, block_size);
+  // The scratch (partial results of split contexts, the launch plan) comes
   // from torch's caching allocator (no hipMalloc in steady state) and is
   // handed back as soon as the launches are queued: the allocator reuses it in
   // stream order, and every launch below is on the current stream.
-  const size_t ws_bytes = pa_decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len);
+  const size_t ws_bytes = pa_decode_workspace_bytes(sh.num_seqs, sh.num_heads, sh.head_size, block_size, max_context_len);
   torch::Tensor workspace;
   if (ws_bytes > 0) {
     workspace = torch::empty({static_cast<int64_t>(ws_bytes)}, query.options().dtype(torch::kUInt8));
   }
   check_status(pa_single_query_cached_kv_attention_ws(
                    out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
-                   block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), num_seqs, num_heads, head_size,
+                   block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs, sh.num_heads, sh.head_size,
                    block_size, static_cast<int>(block_tables.size(1)), max_context_len,
-                   num_seqs > 0 ? query.stride(0) : 0, dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr,
+                   sh.num_seqs > 0 ? query.stride(0) : 0, sh.dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr,
                    ws_bytes, current_stream(query)),
+               what);
+}
+
+// Not part of the reference's module.  The layers of one decode step all see
+// the same context_lens: the caller keeps one workspace for the step (sized by
+// decode_workspace_bytes, a uint8 tensor on the GPU), the first layer passes
+// plan_ready = false and the launch plan is made into it, the others pass
+// true and reuse it.  An empty workspace (size 0) is allowed when none is needed.
+int64_t decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size, int max_context_len) {
+  return static_cast<int64_t>(pa_decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len));
+}
+
+void single_query_cached_kv_attention_planned(
+    torch::Tensor& out, torch::Tensor& query, torch::Tensor& key_cache, torch::Tensor& value_cache, float scale,
+    torch::Tensor& block_tables, torch::Tensor& context_lens, int block_size, int max_context_len,
+    torch::Tensor& workspace, bool plan_ready) {
+  using namespace pa_shim;
+  const char* what = "single_query_cached_kv_attention_planned";
+  const DecodeShape sh = check_decode_args(what, out, query, key_cache, value_cache, block_tables, context_lens, block_size);
+  TORCH_CHECK(workspace.numel() == 0 || (workspace.is_cuda() && workspace.is_contiguous() &&
+                                         workspace.scalar_type() == at::ScalarType::Byte),
+              what, ": workspace must be a contiguous uint8 tensor on the GPU");
+  const size_t ws_bytes = static_cast<size_t>(workspace.numel());
+  check_status(pa_single_query_cached_kv_attention_planned(
+                   out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
+                   block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs, sh.num_heads, sh.head_size,
+                   block_size, static_cast<int>(block_tables.size(1)), max_context_len,
+                   sh.num_seqs > 0 ? query.stride(0) : 0, sh.dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr,
+                   ws_bytes, plan_ready ? 1 : 0, current_stream(query)),
                what);
 }
 
@@ -99,6 +140,10 @@ void multi_query_kv_attention(
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("single_query_cached_kv_attention", &single_query_cached_kv_attention,
         "Attention of one new query token per sequence over the paged key/value cache (MI355X HIP kernel)");
+  m.def("decode_workspace_bytes", &decode_workspace_bytes,
+        "Bytes of workspace single_query_cached_kv_attention_planned wants for these sizes (0 = none)");
+  m.def("single_query_cached_kv_attention_planned", &single_query_cached_kv_attention_planned,
+        "single_query_cached_kv_attention with a workspace whose launch plan is shared by the layers of a step");
   m.def("multi_query_kv_attention", &multi_query_kv_attention,
         "Causal self-attention inside each prompt of a flat token batch (MI355X matrix-core kernel)");
 }

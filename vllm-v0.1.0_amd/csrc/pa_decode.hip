@@ -220,6 +220,9 @@ struct DecodeArgs {
   int num_parts;
   int blocks_per_part;
   int group;  // sequences per work-order group (see the kernel)
+  const int2* row_table;  // balanced order: [8][slots_per_xcd] (sequence, context length), or null = positional order
+  int slots_per_xcd;      // balanced order: a multiple of group
+  int unit;               // balanced order: consecutive sequences that are kept on one XCD (divides group)
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [1] number of pairs, [2] blocks per partition in force ([0] unused)
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
@@ -229,6 +232,9 @@ struct DecodeArgs {
 // non-temporal hint, 0 = never, 2 (default) = per block, see load_tile.
 #ifndef PA_DECODE_NT
 #define PA_DECODE_NT 2
+#endif
+#ifndef PA_DECODE_ITEMS_PLAIN
+#define PA_DECODE_ITEMS_PLAIN 1
 #endif
 
 template <bool STREAM>
@@ -297,48 +303,78 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     if (blockIdx.x < a.list_slots) {
       const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
       if (blockIdx.x >= n_items) return;  // unused slot: one scalar load, then gone
+#if PA_DECODE_ITEMS_PLAIN
+      const unsigned u = blockIdx.x;  // heads fastest: the heads of a pair spread over the XCDs, whose shares stay equal
+#else
       const unsigned u = xcd_contiguous(blockIdx.x, n_items);  // an XCD walks consecutive pairs, all heads of each
+#endif
       const unsigned pair = a.items[u / (unsigned)a.num_heads];
       head_l = (int)(u % (unsigned)a.num_heads);
       seq_l = (int)(pair >> kItemPartBits);
       part = (int)(pair & ((1u << kItemPartBits) - 1u));
+      if (seq_l >= a.num_seqs || part >= a.num_parts) return;  // never true for a list made from these context_lens
       listed = true;
     } else {
       row_id = blockIdx.x - a.list_slots;
       row_count = gridDim.x - a.list_slots;
     }
   }
-  unsigned work = xcd_contiguous(row_id, row_count);
-  if (MODE == kModeParts) {
-    part = work % (unsigned)a.num_parts;
-    work /= (unsigned)a.num_parts;
-  }
   const unsigned G = a.group;
   const unsigned per_group = G * (unsigned)a.num_heads;
-  const unsigned full_groups = (unsigned)a.num_seqs / G;  // a trailing partial group keeps the last place
-  unsigned grp = work / per_group;
-  const unsigned in_grp = work - grp * per_group;
-  if (grp < full_groups) {
-    const unsigned q = full_groups >> 3, rem = full_groups & 7u;  // XCD x owns q + (x < rem) groups
-    const unsigned head_run = rem * (q + 1u);
-    unsigned x, i;
-    if (grp < head_run) {
-      x = grp / (q + 1u);
-      i = grp - x * (q + 1u);
-    } else {
-      x = rem + (grp - head_run) / q;
-      i = (grp - head_run) % q;
+  // kModeList: the partition length in force is the plan kernel's decision
+  const int bpp = MODE == kModeList ? (int)a.counters[2] : a.blocks_per_part;
+  int head, seq, ctx;
+  if (listed) {
+    head = head_l;
+    seq = seq_l;
+    ctx = a.context_lens[seq];
+  } else if (MODE != kModeParts && a.row_table != nullptr) {
+    // Balanced order.  The hardware deals workgroup ids round-robin to the 8
+    // XCDs, and an XCD streams little faster when the others have run dry: the
+    // launch lasts as long as the XCD with the most bytes, and as its longest
+    // row if that row starts late.  pa_decode_plan_kernel therefore places the
+    // sequences by length: row_table[x][i] = (sequence, its context length) of
+    // the i-th sequence XCD x works on, -1 where x has fewer.  The XCD walks
+    // its sequences in chunks of G, ordered (head, sequence) as below.
+    const unsigned x = row_id & 7u, w = row_id >> 3;
+    const unsigned c = w / per_group, in = w - c * per_group;
+    const unsigned hd = in / G;
+    const unsigned i = c * G + (in - hd * G);
+    const int2 e = a.row_table[x * (unsigned)a.slots_per_xcd + i];
+    if ((unsigned)e.x >= (unsigned)a.num_seqs) return;  // an empty slot (-1); also keeps a stale table harmless
+    head = (int)hd;
+    seq = e.x;
+    ctx = e.y;
+  } else {
+    unsigned work = xcd_contiguous(row_id, row_count);
+    if (MODE == kModeParts) {
+      part = work % (unsigned)a.num_parts;
+      work /= (unsigned)a.num_parts;
     }
-    grp = x + 8u * i;
+    const unsigned full_groups = (unsigned)a.num_seqs / G;  // a trailing partial group keeps the last place
+    unsigned grp = work / per_group;
+    const unsigned in_grp = work - grp * per_group;
+    if (grp < full_groups) {
+      const unsigned q = full_groups >> 3, rem = full_groups & 7u;  // XCD x owns q + (x < rem) groups
+      const unsigned head_run = rem * (q + 1u);
+      unsigned x, i;
+      if (grp < head_run) {
+        x = grp / (q + 1u);
+        i = grp - x * (q + 1u);
+      } else {
+        x = rem + (grp - head_run) / q;
+        i = (grp - head_run) % q;
+      }
+      grp = x + 8u * i;
+    }
+    const unsigned gsize = min(G, (unsigned)a.num_seqs - grp * G);  // the last group may be short
+    head = (int)(in_grp / gsize);
+    seq = (int)(grp * G + (in_grp - (in_grp / gsize) * gsize));
+    ctx = a.context_lens[seq];
   }
-  const unsigned gsize = min(G, (unsigned)a.num_seqs - grp * G);  // the last group may be short
-  const int head = listed ? head_l : (int)(in_grp / gsize);
-  const int seq = listed ? seq_l : (int)(grp * G + (in_grp - (in_grp / gsize) * gsize));
 
-  const int ctx = a.context_lens[seq];
   const int nblk_seq = (ctx + B - 1) / B;
   // kModeList: a sequence that fits one partition is finished here, without the workspace
-  const int bpp = MODE == kModeList ? (int)a.counters[2] : a.blocks_per_part;  // the plan kernel's decision
   const bool direct = !PART || (MODE == kModeList && nblk_seq <= bpp);
   const int blk_begin = PART ? part * bpp : 0;
   // the last partition runs to the end of the context even if the context is
@@ -588,75 +624,167 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   }
 }
 
-// Plans kModeList for one batch, from context_lens: one workgroup.
+// Plans one launch from context_lens: one workgroup of kPlanThreads.
 //
-// First the decision whether to split at all.  Partitions exist to keep one
-// long sequence from setting the launch time alone; when the longest sequence
-// is within uniform_pct percent of the mean, rows end together anyway and the
-// second workgroup per row, the workspace round trip and the merge only cost
-// (3-4 % at 256 sequences of exactly 2048 or 4096 tokens).  The partition
-// length in force goes to counters[2] for the decode and merge kernels: the
-// planned one, or kNoSplitBlocks.
-//
-// Then the list of (sequence, partition >= 1) pairs, 256 sequences at a time.
-// A sequence has ceil(blocks / blocks_per_part) partitions, at most max_parts
-// (the last partition then runs to the end of the context).
+// 1. (item-list form) Whether to split at all.  Partitions exist to keep one
+//    long sequence from setting the launch time alone; when the longest
+//    sequence is within uniform_pct percent of the mean, rows end together
+//    anyway and the second workgroup per row, the workspace round trip and the
+//    merge only cost (3-4 % at 256 sequences of exactly 2048 or 4096 tokens).
+//    The partition length in force goes to counters[2] for the decode and
+//    merge kernels: the planned one, or kNoSplitBlocks.
+// 2. (item-list form) The list of (sequence, partition >= 1) pairs.  A
+//    sequence has ceil(blocks / blocks_per_part) partitions, at most max_parts
+//    (the last partition then runs to the end of the context).
+// 3. (balanced order) row_table.  Units of `unit` consecutive sequences
+//    (neighbours in the batch may share physical blocks and should meet in one
+//    L2) are ranked by the blocks their row workgroups will read, heaviest
+//    first, and dealt to the 8 XCDs in a snake (ranks 0..7 -> XCD 0..7,
+//    8..15 -> 7..0, ...), which evens out the XCDs' totals; each XCD then takes
+//    its sequences longest first, so that the launch ends on its shortest
+//    rows.  Ranks come from counting (keys are distinct): no sort needed for
+//    at most kMaxBalancedSeqs sequences.
 constexpr int kNoSplitBlocks = 1 << 24;
+constexpr int kPlanThreads = 1024;
+constexpr int kMaxBalancedSeqs = 1024;  // = kPlanThreads: one sequence per thread
+constexpr int kMaxTableSlots = 8 * (kMaxBalancedSeqs / 8 + 32);
 
-__global__ void __launch_bounds__(256)
-pa_decode_plan_kernel(const int* __restrict__ context_lens, const int num_seqs, const int block_size,
-                      const int blocks_per_part, const int max_parts, const int uniform_pct,
-                      uint32_t* __restrict__ items, unsigned* __restrict__ counters) {
-  __shared__ unsigned scan[256];
-  __shared__ unsigned long long sums[256];
+struct PlanArgs {
+  const int* context_lens;
+  int num_seqs;
+  int block_size;
+  int blocks_per_part;  // planned partition length (item-list form)
+  int max_parts;        // 1 = no item list
+  int uniform_pct;
+  uint32_t* items;
+  unsigned* counters;
+  int2* row_table;      // null = no balanced order
+  int unit;
+  int slots_per_xcd;
+};
+
+// number of keys in [lo, lo + span) among keys[0 .. n), n a multiple of 4 (padding keys are 0 and lo > 0)
+__device__ __forceinline__ unsigned count_in_range(const unsigned* keys, int n, unsigned lo, unsigned span) {
+  unsigned c = 0;
+#pragma unroll 4
+  for (int t = 0; t < n; t += 4) {
+    const u32x4 k = *reinterpret_cast<const u32x4*>(keys + t);
+    c += (k.x - lo < span ? 1u : 0u) + (k.y - lo < span ? 1u : 0u) + (k.z - lo < span ? 1u : 0u) +
+         (k.w - lo < span ? 1u : 0u);
+  }
+  return c;
+}
+
+__global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const PlanArgs p) {
+  __shared__ unsigned scan[kPlanThreads];
+  __shared__ unsigned long long sums[kPlanThreads];
   __shared__ unsigned base;
-  const int tid = threadIdx.x;
-  unsigned long long total = 0;
-  unsigned longest = 0;
-  for (int seq = tid; seq < num_seqs; seq += 256) {
-    const unsigned nblk = (unsigned)((max(context_lens[seq], 0) + block_size - 1) / block_size);
-    total += nblk;
-    longest = max(longest, nblk);
-  }
-  sums[tid] = total;
-  scan[tid] = longest;
-  if (tid == 0) base = 0;
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if (tid < off) {
-      sums[tid] += sums[tid + off];
-      scan[tid] = max(scan[tid], scan[tid + off]);
+  __shared__ __attribute__((aligned(16))) unsigned seq_key[kMaxBalancedSeqs + 4];
+  __shared__ __attribute__((aligned(16))) unsigned unit_key[kMaxBalancedSeqs + 4];
+  __shared__ int table[kMaxTableSlots];
+  const int tid = threadIdx.x, nthreads = blockDim.x;  // nthreads: a power of two
+  const int num_seqs = p.num_seqs, block_size = p.block_size;
+  int bpp = kNoSplitBlocks;
+  if (p.max_parts > 1) {
+    unsigned long long total = 0;
+    unsigned longest = 0;
+    for (int seq = tid; seq < num_seqs; seq += nthreads) {
+      const unsigned nblk = (unsigned)((max(p.context_lens[seq], 0) + block_size - 1) / block_size);
+      total += nblk;
+      longest = max(longest, nblk);
     }
+    sums[tid] = total;
+    scan[tid] = longest;
+    if (tid == 0) base = 0;
     __syncthreads();
-  }
-  const bool uniform = (unsigned long long)scan[0] * 100ull * (unsigned)num_seqs <= sums[0] * (unsigned long long)uniform_pct;
-  const int bpp = uniform ? kNoSplitBlocks : blocks_per_part;
-  __syncthreads();
-  for (int s0 = 0; s0 < num_seqs; s0 += 256) {
-    const int seq = s0 + tid;
-    unsigned extra = 0;
-    if (seq < num_seqs) {
-      const int nblk = (max(context_lens[seq], 0) + block_size - 1) / block_size;
-      extra = (unsigned)(min(max((nblk + bpp - 1) / bpp, 1), max_parts) - 1);
-    }
-    scan[tid] = extra;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {  // inclusive scan
-      const unsigned add = tid >= off ? scan[tid - off] : 0u;
-      __syncthreads();
-      scan[tid] += add;
+    for (int off = nthreads / 2; off >= 1; off >>= 1) {
+      if (tid < off) {
+        sums[tid] += sums[tid + off];
+        scan[tid] = max(scan[tid], scan[tid + off]);
+      }
       __syncthreads();
     }
-    const unsigned first = base + scan[tid] - extra;
-    for (unsigned p = 0; p < extra; p++) items[first + p] = ((uint32_t)seq << kItemPartBits) | (p + 1u);
+    const bool uniform =
+        (unsigned long long)scan[0] * 100ull * (unsigned)num_seqs <= sums[0] * (unsigned long long)p.uniform_pct;
+    bpp = uniform ? kNoSplitBlocks : p.blocks_per_part;
     __syncthreads();
-    if (tid == 255) base += scan[255];
-    __syncthreads();
+    for (int s0 = 0; s0 < num_seqs; s0 += nthreads) {
+      const int seq = s0 + tid;
+      unsigned extra = 0;
+      if (seq < num_seqs) {
+        const int nblk = (max(p.context_lens[seq], 0) + block_size - 1) / block_size;
+        extra = (unsigned)(min(max((nblk + bpp - 1) / bpp, 1), p.max_parts) - 1);
+      }
+      scan[tid] = extra;
+      __syncthreads();
+      for (int off = 1; off < nthreads; off <<= 1) {  // inclusive scan
+        const unsigned add = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+      }
+      const unsigned first = base + scan[tid] - extra;
+      for (unsigned q = 0; q < extra; q++) p.items[first + q] = ((uint32_t)seq << kItemPartBits) | (q + 1u);
+      __syncthreads();
+      if (tid == nthreads - 1) base += scan[nthreads - 1];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      p.counters[0] = 0u;
+      p.counters[1] = base;
+      p.counters[2] = (unsigned)bpp;
+    }
   }
-  if (tid == 0) {
-    counters[0] = 0u;
-    counters[1] = base;
-    counters[2] = (unsigned)bpp;
+  if (p.row_table == nullptr) return;
+
+  // ---- balanced order (num_seqs <= kMaxBalancedSeqs <= nthreads... one sequence per thread) ----
+  // Keys: [31:29] XCD (sequence keys only, filled in below), [28:10] weight in
+  // blocks, [9:0] 1023 - index.  Distinct and non-zero; ties go to batch order.
+  const int U = p.unit, NX = p.slots_per_xcd;
+  const int n_units = (num_seqs + U - 1) / U;
+  int my_ctx = 0;
+  unsigned my_weight = 0;
+  if (tid < num_seqs) {
+    my_ctx = p.context_lens[tid];
+    my_weight = (unsigned)min((max(my_ctx, 0) + block_size - 1) / block_size, min(bpp, (1 << 17) - 1));
+    scan[tid] = my_weight;
+  }
+  if (tid < 4) {  // padding of the last vector of four keys
+    seq_key[((num_seqs + 3) & ~3) - 1 - tid] = 0u;
+    unit_key[((n_units + 3) & ~3) - 1 - tid] = 0u;
+  }
+  for (int i = tid; i < 8 * NX; i += nthreads) table[i] = -1;
+  __syncthreads();
+  if (tid < n_units) {
+    unsigned weight = 0;
+    for (int e = 0; e < U; e++)
+      if (tid * U + e < num_seqs) weight += scan[tid * U + e];
+    unit_key[tid] = (min(weight, (1u << 19) - 1u) << 10) | (unsigned)(kMaxBalancedSeqs - 1 - tid);
+  }
+  __syncthreads();
+  if (tid < n_units) {
+    const unsigned key = unit_key[tid];
+    const unsigned rank = count_in_range(unit_key, (n_units + 3) & ~3, key + 1u, ~key);  // keys above this one
+    const unsigned row = rank >> 3, col = rank & 7u;
+    const unsigned x = (row & 1u) ? 7u - col : col;
+    for (int e = 0; e < U; e++) {
+      const int sq = tid * U + e;
+      if (sq < num_seqs) seq_key[sq] = (x << 29) | (scan[sq] << 10) | (unsigned)(kMaxBalancedSeqs - 1 - sq);
+    }
+  }
+  __syncthreads();
+  if (tid < num_seqs) {
+    const unsigned key = seq_key[tid];
+    const unsigned top = (key | 0x1fffffffu);  // the largest key of the same XCD
+    const unsigned place = count_in_range(seq_key, (num_seqs + 3) & ~3, key + 1u, top - key);  // same XCD, above
+    table[(key >> 29) * NX + place] = tid;  // place < units on that XCD * U <= NX
+  }
+  __syncthreads();
+  if (tid < num_seqs) scan[tid] = (unsigned)my_ctx;
+  __syncthreads();
+  for (int i = tid; i < 8 * NX; i += nthreads) {
+    const int sq = table[i];
+    p.row_table[i] = make_int2(sq, sq >= 0 ? (int)scan[sq] : 0);
   }
 }
 
@@ -731,6 +859,12 @@ pa_decode_merge_kernel(const DecodeArgs a, const int planned_tokens_per_part, co
 // ---- host side ----------------------------------------------------------------
 
 constexpr int kNumWaves = 4;
+constexpr int kBalanceUnit = 4;       // balanced order: consecutive sequences per unit
+constexpr double kBalancePerCallBytes = 2e9;
+// who makes the plan (item list, row table) that sits at the head of the workspace
+constexpr int kPlanPerCall = 0;  // this call, for itself
+constexpr int kPlanShared = 1;   // this call, for itself and later calls on the same context_lens
+constexpr int kPlanReady = 2;    // an earlier call did
 constexpr int kListUniformPct = 125;  // kModeList: no partitions while the longest context <= 1.25 x the mean
 
 // Waves per workgroup: 4, except head size 64, whose rows stream a quarter of
@@ -746,28 +880,46 @@ constexpr int kListUniformPct = 125;  // kModeList: no partitions while the long
 #endif
 
 template <typename E, int D, int B>
-static int launch(const DecodeArgs& a, int tokens_per_part, hipStream_t stream) {
+static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hipStream_t stream) {
   constexpr int NW = D <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
+  // workgroups of the row pass: in the balanced order every XCD gets slots_per_xcd sequences' worth
+  const unsigned row_wgs = a.row_table != nullptr ? 8u * (unsigned)a.slots_per_xcd * (unsigned)a.num_heads : rows;
+  const bool list = a.num_parts > 1 && a.items != nullptr;
+  if ((list || a.row_table != nullptr) && !plan_ready) {
+    static const int uniform_pct = [] {
+      const char* e = getenv("PA_DECODE_LIST_UNIFORM_PCT");  // tuning aid only: 0 = always split
+      return e ? atoi(e) : kListUniformPct;
+    }();
+    PlanArgs p;
+    p.context_lens = a.context_lens;
+    p.num_seqs = a.num_seqs;
+    p.block_size = B;
+    p.blocks_per_part = a.blocks_per_part;
+    p.max_parts = list ? a.num_parts : 1;
+    p.uniform_pct = uniform_pct;
+    p.items = const_cast<uint32_t*>(a.items);
+    p.counters = a.counters;
+    p.row_table = const_cast<int2*>(a.row_table);
+    p.unit = a.unit;
+    p.slots_per_xcd = a.slots_per_xcd;
+    int plan_threads = 256;  // a power of two; the balanced order wants one thread per sequence
+    while (plan_threads < kPlanThreads && plan_threads < a.num_seqs) plan_threads *= 2;
+    hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(plan_threads), 0, stream, p);
+    PA_CHECK_LAUNCH("pa_decode_plan_kernel launch");
+  }
   if (a.num_parts <= 1) {
-    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeRows>), dim3(rows), dim3(NW * 64), 0, stream, a);
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeRows>), dim3(row_wgs), dim3(NW * 64), 0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel launch");
-  } else if (a.items == nullptr) {
+  } else if (!list) {
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeParts>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64),
                        0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (partitioned) launch");
     hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 0);
     PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   } else {
-    static const int uniform_pct = [] {
-      const char* e = getenv("PA_DECODE_LIST_UNIFORM_PCT");  // tuning aid only: 0 = always split
-      return e ? atoi(e) : kListUniformPct;
-    }();
-    hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(256), 0, stream, a.context_lens, a.num_seqs, B,
-                       a.blocks_per_part, a.num_parts, uniform_pct, const_cast<uint32_t*>(a.items), a.counters);
-    PA_CHECK_LAUNCH("pa_decode_plan_kernel launch");
-    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeList>), dim3(a.list_slots + rows), dim3(NW * 64), 0, stream,
-                       a);
+    hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeList>), dim3(a.list_slots + row_wgs), dim3(NW * 64), 0,
+                       stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (item list) launch");
     hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 1);
     PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
@@ -776,22 +928,22 @@ static int launch(const DecodeArgs& a, int tokens_per_part, hipStream_t stream) 
 }
 
 template <typename E, int D>
-static int dispatch_block(int B, const DecodeArgs& a, int tpp, hipStream_t st) {
+static int dispatch_block(int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
   switch (B) {
-    case 8: return launch<E, D, 8>(a, tpp, st);
-    case 16: return launch<E, D, 16>(a, tpp, st);
-    case 32: return launch<E, D, 32>(a, tpp, st);
+    case 8: return launch<E, D, 8>(a, tpp, plan_ready, st);
+    case 16: return launch<E, D, 16>(a, tpp, plan_ready, st);
+    case 32: return launch<E, D, 32>(a, tpp, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported block size: %d (supported: 8, 16, 32)", B);
   }
 }
 
 template <typename E>
-static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, hipStream_t st) {
+static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
   switch (D) {
-    case 64: return dispatch_block<E, 64>(B, a, tpp, st);
-    case 80: return dispatch_block<E, 80>(B, a, tpp, st);
-    case 96: return dispatch_block<E, 96>(B, a, tpp, st);
-    case 128: return dispatch_block<E, 128>(B, a, tpp, st);
+    case 64: return dispatch_block<E, 64>(B, a, tpp, plan_ready, st);
+    case 80: return dispatch_block<E, 80>(B, a, tpp, plan_ready, st);
+    case 96: return dispatch_block<E, 96>(B, a, tpp, plan_ready, st);
+    case 128: return dispatch_block<E, 128>(B, a, tpp, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported head size: %d (supported: 64, 80, 96, 128)", D);
   }
 }
@@ -806,7 +958,35 @@ struct PartitionPlan {
   int num_parts;
   int blocks_per_part;
   bool list;  // kModeList: partitions of a fixed length, as many as each sequence needs
+  // balanced order of the row workgroups (rows and item-list forms); slots_per_xcd = 0: positional order
+  int group = 0, unit = 0, slots_per_xcd = 0;
 };
+
+// Sequences per work-order group: ~128 workgroups are resident per XCD (32 CUs
+// x 4), and group * num_heads of them should span every head.
+static int group_for(int num_heads) { return 128 / num_heads < 1 ? 1 : (128 / num_heads > 16 ? 16 : 128 / num_heads); }
+
+// Balanced order: units of up to kBalanceUnit consecutive sequences, for
+// batches of at least two units per XCD and at most kMaxBalancedSeqs sequences
+// (beyond that the XCDs' shares even out by themselves, and the plan kernel's
+// counting would take longer than it saves).
+static void plan_balance(PartitionPlan& p, int num_seqs, int num_heads) {
+  static const int balance = [] {
+    const char* e = getenv("PA_DECODE_BALANCE");  // tuning aid only: 0 = positional order, n = units of n sequences
+    return e ? atoi(e) : kBalanceUnit;
+  }();
+  if (balance <= 0 || num_seqs > kMaxBalancedSeqs) return;
+  int group = group_for(num_heads);
+  const int unit = balance < group ? balance : group;
+  group = group / unit * unit;
+  const int units = (num_seqs + unit - 1) / unit;
+  if (units < 16) return;
+  const int slots = ((units + 7) / 8 * unit + group - 1) / group * group;
+  if (8 * slots > kMaxTableSlots) return;
+  p.group = group;
+  p.unit = unit;
+  p.slots_per_xcd = slots;
+}
 
 // kModeList: partitions of at least this many tokens, at most kListMaxParts of
 // them, for every batch of more than 256 rows whose longest context exceeds one
@@ -842,8 +1022,13 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   const bool long_contexts = max_blocks > list_bpp;  // some sequence can have a second partition
   if (want <= 1 && list_mode != 0 && long_contexts && num_seqs < (1 << (32 - kItemPartBits))) {
     const int parts = (max_blocks + list_bpp - 1) / list_bpp;
-    if (parts > 1 && rows * parts < (1ll << 31)) return PartitionPlan{parts, list_bpp, true};
+    if (parts > 1 && rows * parts < (1ll << 31)) {
+      PartitionPlan lp = {parts, list_bpp, true};
+      plan_balance(lp, num_seqs, num_heads);
+      return lp;
+    }
   }
+  if (want <= 1) plan_balance(p, num_seqs, num_heads);  // one workgroup per row: a big batch, or short contexts
   if (want <= 1 || max_blocks <= min_blocks) return p;
   int bpp = (max_blocks + want - 1) / want;
   if (bpp < min_blocks) bpp = min_blocks;
@@ -854,19 +1039,22 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   return p;
 }
 
-// Workspace: accumulators [rows * parts][D], then (max, sum) pairs
-// [rows * parts][2], fp32; kModeList appends the item list [num_seqs * parts]
-// and the three counters.
-static size_t workspace_bytes_for(int64_t rows, int num_parts, int head_size, int64_t list_seqs) {
-  size_t n = (size_t)rows * num_parts * (head_size + 2) * sizeof(float);
-  if (list_seqs > 0) n += (size_t)list_seqs * num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
+// Workspace: the balanced order's row table [8][slots_per_xcd] of int2 first
+// (if any); with partitions, accumulators [rows * parts][D], then (max, sum)
+// pairs [rows * parts][2], fp32; kModeList appends the item list
+// [num_seqs * parts] and the three counters.
+static size_t workspace_bytes_for(int64_t rows, const PartitionPlan& p, int head_size, int64_t num_seqs) {
+  size_t n = (size_t)8 * p.slots_per_xcd * sizeof(int2);
+  if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float);
+  if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * p.num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
   return n;
 }
 
 static int decode_entry(void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
                         const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads,
                         int head_size, int block_size, int max_num_blocks_per_seq, int max_context_len,
-                        int64_t q_stride, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t q_stride, int dtype, void* workspace, size_t workspace_bytes, int plan_mode,
+                        void* stream) {
   clear_error();
   PA_REQUIRE(num_seqs >= 0 && num_heads >= 0, "negative num_seqs (%d) or num_heads (%d)", num_seqs, num_heads);
   if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
@@ -906,32 +1094,51 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.q_vec_ok = aligned16(query) && ((q_stride * (int64_t)es) % 16 == 0) && ((head_size * es) % 16 == 0);
   a.num_parts = 1;
   a.blocks_per_part = max_num_blocks_per_seq;
-  // ~128 workgroups are resident per XCD (32 CUs x 4): G * num_heads of them
-  // should span every head
-  a.group = 128 / num_heads < 1 ? 1 : (128 / num_heads > 16 ? 16 : 128 / num_heads);
+  a.group = group_for(num_heads);
+  a.row_table = nullptr;
+  a.slots_per_xcd = 0;
+  a.unit = 1;
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
-    const PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
-    if (p.num_parts > 1 && rows * p.num_parts < (1ll << 31) &&
-        workspace_bytes_for(rows, p.num_parts, head_size, p.list ? num_seqs : 0) <= workspace_bytes) {
-      a.num_parts = p.num_parts;
-      a.blocks_per_part = p.blocks_per_part;
-      a.ws_acc = static_cast<float*>(workspace);
-      a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
-      if (p.list) {
-        uint32_t* tail = reinterpret_cast<uint32_t*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
-        a.items = tail;
-        a.counters = tail + (size_t)num_seqs * p.num_parts;
-        a.list_slots = (unsigned)(rows * (p.num_parts - 1));
+    PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) p.slots_per_xcd = 0;  // the table holds 8-byte entries
+    if (rows * p.num_parts >= (1ll << 31)) p = PartitionPlan{1, p.blocks_per_part, false};
+    if (workspace_bytes_for(rows, p, head_size, num_seqs) > workspace_bytes) p.slots_per_xcd = 0;  // retry without the table
+    if ((p.num_parts > 1 || p.slots_per_xcd > 0) && workspace_bytes_for(rows, p, head_size, num_seqs) <= workspace_bytes) {
+      char* base = static_cast<char*>(workspace);
+      if (p.slots_per_xcd > 0) {
+        // A plan made for this call alone has to earn its few microseconds: only for
+        // launches that stream a couple of gigabytes.  A plan shared by the layers of
+        // a step always pays.
+        const double streamed = 2.0 * (double)rows * max_context_len * head_size * es;
+        if (plan_mode != kPlanPerCall || streamed >= kBalancePerCallBytes) {
+          a.row_table = reinterpret_cast<const int2*>(base);
+          a.slots_per_xcd = p.slots_per_xcd;
+          a.unit = p.unit;
+          a.group = p.group;
+        }
+        base += (size_t)8 * p.slots_per_xcd * sizeof(int2);
+      }
+      if (p.num_parts > 1) {
+        a.num_parts = p.num_parts;
+        a.blocks_per_part = p.blocks_per_part;
+        a.ws_acc = reinterpret_cast<float*>(base);
+        a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
+        if (p.list) {
+          uint32_t* tail = reinterpret_cast<uint32_t*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
+          a.items = tail;
+          a.counters = tail + (size_t)num_seqs * p.num_parts;
+          a.list_slots = (unsigned)(rows * (p.num_parts - 1));
+        }
       }
     }
   }
   const int tokens_per_part = a.blocks_per_part * block_size;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, tokens_per_part, st);
-    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, tokens_per_part, st);
-    default: return dispatch_head<ElemBF16>(head_size, block_size, a, tokens_per_part, st);
+    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
+    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
+    default: return dispatch_head<ElemBF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
   }
 }
 
@@ -943,15 +1150,14 @@ extern "C" int pa_single_query_cached_kv_attention(
     int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* stream) {
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, nullptr, 0,
-                          stream);
+                          pa::kPlanPerCall, stream);
 }
 
 extern "C" size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size,
                                             int max_context_len) {
   if (num_seqs <= 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0 || max_context_len <= 0) return 0;
   const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
-  if (p.num_parts <= 1) return 0;
-  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p.num_parts, head_size, p.list ? num_seqs : 0);
+  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p, head_size, num_seqs);
 }
 
 extern "C" int pa_single_query_cached_kv_attention_ws(
@@ -961,5 +1167,15 @@ extern "C" int pa_single_query_cached_kv_attention_ws(
     size_t workspace_bytes, void* stream) {
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
-                          workspace_bytes, stream);
+                          workspace_bytes, pa::kPlanPerCall, stream);
+}
+
+extern "C" int pa_single_query_cached_kv_attention_planned(
+    void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
+    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* workspace,
+    size_t workspace_bytes, int plan_ready, void* stream) {
+  return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
+                          head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
+                          workspace_bytes, plan_ready ? pa::kPlanReady : pa::kPlanShared, stream);
 }

@@ -10,7 +10,8 @@ batch
   1. prompt tokens: causal self-attention per prompt, no cache read (:115-122);
   2. wait for the cache engine's swap of this layer (:125-126);
   3. reshape_and_cache on [:num_valid_tokens] (:131-140);
-  4. single_query_cached_kv_attention on the generation tokens (:142-152).
+  4. single_query_cached_kv_attention on the generation tokens (:142-152);
+     its launch plan is shared by the layers of a step (see below).
 
 Steps 1, 3 and 4 are the HIP operator modules.  For step 1 the reference calls
 xformers' CUTLASS kernel with a block-diagonal causal mask (:59-67); here it is
@@ -65,17 +66,26 @@ class PagedAttention(nn.Module):
         input_metadata: InputMetadata,
     ) -> None:
         block_size = value_cache.shape[3]
-        self._attention_ops.single_query_cached_kv_attention(
-            output,
-            query,
-            key_cache,
-            value_cache,
-            self.scale,
-            input_metadata.block_tables,
-            input_metadata.context_lens,
-            block_size,
-            input_metadata.max_context_len,
-        )
+        planned = getattr(self._attention_ops, "single_query_cached_kv_attention_planned", None)
+        if planned is None:  # a module with the reference's functions only
+            self._attention_ops.single_query_cached_kv_attention(
+                output, query, key_cache, value_cache, self.scale, input_metadata.block_tables,
+                input_metadata.context_lens, block_size, input_metadata.max_context_len)
+            return
+        # Every layer of a step sees the same context_lens: the launch plan that
+        # depends on them alone (row order, partitions of long contexts) is made
+        # by the first layer into a workspace that lives on the step's
+        # InputMetadata, and reused by the others.
+        key = (query.shape[0], self.num_heads, self.head_size, block_size, input_metadata.max_context_len,
+               query.device)
+        cached = getattr(input_metadata, "_decode_workspace", None)
+        plan_ready = cached is not None and cached[0] == key
+        if not plan_ready:
+            nbytes = self._attention_ops.decode_workspace_bytes(*key[:5])
+            cached = (key, torch.empty(nbytes, dtype=torch.uint8, device=query.device))
+            input_metadata._decode_workspace = cached
+        planned(output, query, key_cache, value_cache, self.scale, input_metadata.block_tables,
+                input_metadata.context_lens, block_size, input_metadata.max_context_len, cached[1], plan_ready)
 
     def forward(
         self,
