@@ -24,15 +24,25 @@ def row_table(blocks, unit, slots):
     n_units = (S + unit - 1) // unit
     seq_key = [(min(b, (1 << 20) - 1) << 10) | (1023 - s) for s, b in enumerate(blocks)]
     unit_key = [(min(sum(blocks[u * unit:(u + 1) * unit]), (1 << 22) - 1) << 10) | (1023 - u) for u in range(n_units)]
-    unit_xcd = []
+    full_rows = n_units >> 3
+    seq_xcd = [None] * S
+    tail = []
     for u in range(n_units):
         rank = sum(k > unit_key[u] for k in unit_key)
         row, col = divmod(rank, 8)
-        unit_xcd.append(7 - col if row & 1 else col)
+        for s in range(u * unit, min((u + 1) * unit, S)):
+            if row < full_rows:
+                seq_xcd[s] = 7 - col if row & 1 else col
+            else:
+                tail.append(s)  # units of the partial last row: their sequences are dealt one by one
+    for s in tail:
+        rank = sum(seq_key[t] > seq_key[s] for t in tail)
+        row, col = full_rows + rank // 8, rank % 8
+        seq_xcd[s] = 7 - col if row & 1 else col
     table = [[-1] * slots for _ in range(8)]
     for s in range(S):
-        x = unit_xcd[s // unit]
-        place = sum(seq_key[t] > seq_key[s] for t in range(S) if unit_xcd[t // unit] == x)
+        x = seq_xcd[s]
+        place = sum(seq_key[t] > seq_key[s] for t in range(S) if seq_xcd[t] == x)
         assert table[x][place] == -1
         table[x][place] = s
     return table
@@ -81,3 +91,10 @@ def test_balanced_order_evens_out_the_xcd_shares_and_runs_longest_first():
             assert all(min(blocks[s] for s in a) >= max(blocks[s] for s in b) for a, b in zip(chunks, chunks[1:]))
     # batch order deals 1.26 on average (up to 1.5) for these lengths
     assert np.mean(ratios) < 1.08 and max(ratios) < 1.2
+
+
+@pytest.mark.parametrize("S,H", [(100, 40), (100, 32), (200, 32), (77, 12), (61, 32)])
+def test_balanced_order_of_equal_lengths_gives_no_xcd_more_than_its_share(S, H):
+    """Equal lengths: the fullest XCD holds ceil(S / 8) sequences, not a whole unit more."""
+    counts = [len(rows) // H for rows in rows_visited(S, H, [64] * S).values()]
+    assert sum(counts) == S and max(counts) == -(-S // 8), counts

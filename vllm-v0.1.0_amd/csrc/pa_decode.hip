@@ -681,6 +681,7 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
   __shared__ unsigned base;
   __shared__ __attribute__((aligned(16))) unsigned seq_key[kMaxBalancedSeqs + 4];
   __shared__ __attribute__((aligned(16))) unsigned unit_key[kMaxBalancedSeqs + 4];
+  __shared__ __attribute__((aligned(16))) unsigned tail_key[kMaxBalancedSeqs + 4];
   __shared__ int table[kMaxTableSlots];
   const int tid = threadIdx.x, nthreads = blockDim.x;  // nthreads: a power of two
   const int num_seqs = p.num_seqs, block_size = p.block_size;
@@ -751,6 +752,7 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
   }
   if (tid < 4) {  // padding of the last vector of four keys
     seq_key[((num_seqs + 3) & ~3) - 1 - tid] = 0u;
+    tail_key[((num_seqs + 3) & ~3) - 1 - tid] = 0u;
     unit_key[((n_units + 3) & ~3) - 1 - tid] = 0u;
   }
   for (int i = tid; i < 8 * NX; i += nthreads) table[i] = -1;
@@ -762,6 +764,10 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
     unit_key[tid] = (min(weight, (1u << 19) - 1u) << 10) | (unsigned)(kMaxBalancedSeqs - 1 - tid);
   }
   __syncthreads();
+  // Whole rows of 8 ranks are dealt as units.  The units of the last, partial
+  // row (the lightest ones) are taken apart and their sequences dealt one by
+  // one, so that the XCDs' sequence counts differ by one at most, not by a unit.
+  const unsigned full_rows = (unsigned)n_units >> 3;
   if (tid < n_units) {
     const unsigned key = unit_key[tid];
     const unsigned rank = count_in_range(unit_key, (n_units + 3) & ~3, key + 1u, ~key);  // keys above this one
@@ -769,15 +775,25 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
     const unsigned x = (row & 1u) ? 7u - col : col;
     for (int e = 0; e < U; e++) {
       const int sq = tid * U + e;
-      if (sq < num_seqs) seq_key[sq] = (x << 29) | (scan[sq] << 10) | (unsigned)(kMaxBalancedSeqs - 1 - sq);
+      if (sq >= num_seqs) break;
+      const unsigned own = (scan[sq] << 10) | (unsigned)(kMaxBalancedSeqs - 1 - sq);
+      seq_key[sq] = row < full_rows ? (x << 29) | own : 0u;
+      tail_key[sq] = row < full_rows ? 0u : own;
     }
+  }
+  __syncthreads();
+  if (tid < num_seqs && tail_key[tid] != 0u) {
+    const unsigned key = tail_key[tid];
+    const unsigned rank = count_in_range(tail_key, (num_seqs + 3) & ~3, key + 1u, ~key);
+    const unsigned row = full_rows + (rank >> 3), col = rank & 7u;
+    seq_key[tid] = (((row & 1u) ? 7u - col : col) << 29) | key;
   }
   __syncthreads();
   if (tid < num_seqs) {
     const unsigned key = seq_key[tid];
     const unsigned top = (key | 0x1fffffffu);  // the largest key of the same XCD
     const unsigned place = count_in_range(seq_key, (num_seqs + 3) & ~3, key + 1u, top - key);  // same XCD, above
-    table[(key >> 29) * NX + place] = tid;  // place < units on that XCD * U <= NX
+    table[(key >> 29) * NX + place] = tid;  // place < ceil(units / 8) * U <= NX
   }
   __syncthreads();
   if (tid < num_seqs) scan[tid] = (unsigned)my_ctx;
