@@ -233,9 +233,6 @@ struct DecodeArgs {
 #ifndef PA_DECODE_NT
 #define PA_DECODE_NT 2
 #endif
-#ifndef PA_DECODE_ITEMS_PLAIN
-#define PA_DECODE_ITEMS_PLAIN 1
-#endif
 
 template <bool STREAM>
 __device__ __forceinline__ u32x4 load16(const char* p) {
@@ -303,11 +300,9 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     if (blockIdx.x < a.list_slots) {
       const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
       if (blockIdx.x >= n_items) return;  // unused slot: one scalar load, then gone
-#if PA_DECODE_ITEMS_PLAIN
-      const unsigned u = blockIdx.x;  // heads fastest: the heads of a pair spread over the XCDs, whose shares stay equal
-#else
-      const unsigned u = xcd_contiguous(blockIdx.x, n_items);  // an XCD walks consecutive pairs, all heads of each
-#endif
+      // heads fastest: the heads of a pair spread over the XCDs, whose shares of the listed work
+      // are thereby equal (an XCD walking whole pairs measured the same on random lengths)
+      const unsigned u = blockIdx.x;
       const unsigned pair = a.items[u / (unsigned)a.num_heads];
       head_l = (int)(u % (unsigned)a.num_heads);
       seq_l = (int)(pair >> kItemPartBits);
