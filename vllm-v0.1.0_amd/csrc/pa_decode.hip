@@ -223,6 +223,7 @@ struct DecodeArgs {
   const int2* row_table;  // balanced order: [8][slots_per_xcd] (sequence, context length), or null = positional order
   int slots_per_xcd;      // balanced order: a multiple of group
   int unit;               // balanced order: consecutive sequences that are kept on one XCD (divides group)
+  int plain_order;        // positional order with heads fastest (few rows)
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [1] number of pairs, [2] blocks per partition in force ([0] unused)
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
@@ -340,6 +341,12 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     head = (int)hd;
     seq = e.x;
     ctx = e.y;
+  } else if (MODE != kModeParts && a.plain_order) {
+    // Few rows (all resident at once): heads fastest, so that every XCD gets an
+    // eighth of every sequence's heads whatever the lengths are.
+    seq = (int)(row_id / (unsigned)a.num_heads);
+    head = (int)(row_id - (unsigned)seq * (unsigned)a.num_heads);
+    ctx = a.context_lens[seq];
   } else {
     unsigned work = xcd_contiguous(row_id, row_count);
     if (MODE == kModeParts) {
@@ -872,6 +879,7 @@ pa_decode_merge_kernel(const DecodeArgs a, const int planned_tokens_per_part, co
 constexpr int kNumWaves = 4;
 constexpr int kBalanceUnit = 4;       // balanced order: consecutive sequences per unit
 constexpr double kBalancePerCallBytes = 2e9;
+constexpr int kPlainOrderRows = 2048;
 // who makes the plan (item list, row table) that sits at the head of the workspace
 constexpr int kPlanPerCall = 0;  // this call, for itself
 constexpr int kPlanShared = 1;   // this call, for itself and later calls on the same context_lens
@@ -1109,6 +1117,11 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.row_table = nullptr;
   a.slots_per_xcd = 0;
   a.unit = 1;
+  static const int plain_rows = [] {
+    const char* e = getenv("PA_DECODE_PLAIN_ROWS");  // tuning aid only
+    return e ? atoi(e) : kPlainOrderRows;
+  }();
+  a.plain_order = rows <= plain_rows ? 1 : 0;
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
