@@ -25,6 +25,12 @@ tokenizer, no checkpoint can be fetched here).
     tokens/s.
 
     python tools/bench_throughput.py [--model 7b|13b|tiny] [--num-prompts 1000] [--json out.json]
+
+Device time per operator class: run the same command under
+`rocprofv3 --kernel-trace --stats --output-format csv` and give the
+*_kernel_stats.csv to tools/summarize_kernel_classes.py; the result's
+paged_attention_kv_bytes over the pa_decode_* time is the bandwidth the paged
+attention reached on these batches.
 """
 from __future__ import annotations
 
@@ -125,7 +131,7 @@ def build_model(pkg, cfg, dtype, device, block_size, num_blocks, max_position):
 
 
 def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_num_seqs=256, block_size=16,
-        num_blocks=0, dtype_name="float16", device="cuda:0", verbose=True, profile_steps=0, profile_from=300):
+        num_blocks=0, dtype_name="float16", device="cuda:0", verbose=True):
     import torch
     import __graft_entry__
 
@@ -155,21 +161,9 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
 
     steps = prompt_steps = 0
     step_log = []
-    prof = None
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     while waiting or running:
-        if profile_steps and steps == profile_from:
-            from torch.profiler import ProfilerActivity, profile
-            prof = profile(activities=[ProfilerActivity.CUDA])
-            prof.__enter__()
-            t_prof = time.perf_counter()
-        if prof is not None and steps == profile_from + profile_steps:
-            torch.cuda.synchronize()
-            wall_prof = time.perf_counter() - t_prof
-            prof.__exit__(None, None, None)
-            classes = operator_classes(prof, profile_steps)
-            prof = None
         # one new slot for every running sequence (its last sampled token is written this step)
         for s in running:
             if len(s.table) * B < s.get_len():
@@ -194,6 +188,7 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
             batched += s.get_len()
         groups = [SimpleNamespace(request_id=str(i), is_prompt=i < len(admitted), seq_data={i: s}, sampling_params=None,
                                   block_tables={i: s.table}) for i, s in enumerate(admitted + running)]
+        gen_ctx_tokens = sum(s.get_len() for s in running)  # context tokens the paged attention reads this step
         t0 = time.perf_counter()
         tokens, positions, meta = prepare_inputs(groups, B, device=device)
         ends = np.cumsum([s.get_len() for s in admitted]) - 1 if admitted else np.zeros(0, dtype=np.int64)
@@ -216,13 +211,13 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
         running = still
         steps += 1
         prompt_steps += bool(admitted)
-        step_log.append((len(admitted), n_prompt_tokens, len(order) - len(admitted), time.perf_counter() - t0))
+        step_log.append((len(admitted), n_prompt_tokens, len(order) - len(admitted), time.perf_counter() - t0, gen_ctx_tokens))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
 
     total_prompt = sum(p for p, _ in requests)
     total_output = sum(o for _, o in requests)
-    decode_only = [t for a, _, n, t in step_log if a == 0 and n >= max_num_seqs - 8]
+    decode_only = [t for a, _, n, t, _ in step_log if a == 0 and n >= max_num_seqs - 8]
     result = {
         "benchmark": "benchmark_throughput.py restated with synthetic requests",
         "model": f"LLaMA-{model} shape, random weights, {dtype_name}",
@@ -235,42 +230,14 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
         "total_tokens_per_s": (total_prompt + total_output) / elapsed,
         "output_tokens_per_s": total_output / elapsed,
         "full_batch_decode_step_ms": 1e3 * float(np.median(decode_only)) if decode_only else None,
+        # what the paged attention had to read over the whole run: K and V of every context token, every layer
+        "context_tokens_read": int(sum(w[4] for w in step_log)),
+        "paged_attention_kv_bytes": int(sum(w[4] for w in step_log)) * 2 * H * D * L
+                                    * torch.tensor([], dtype=dtype).element_size(),
     }
-    if profile_steps and steps > profile_from + profile_steps:
-        window = step_log[profile_from:profile_from + profile_steps]
-        result["profiled_window"] = {
-            "steps": profile_steps, "from_step": profile_from,
-            "note": "elapsed_s and the rates above include the profiler's overhead in this window",
-            "mean_prompt_tokens_per_step": float(np.mean([n for _, n, _, _ in window])),
-            "mean_generation_tokens_per_step": float(np.mean([n for _, _, n, _ in window])),
-            "wall_ms_per_step": 1e3 * wall_prof / profile_steps,
-            "device_ms_per_step_by_operator_class": classes,
-        }
     if verbose:
         print(json.dumps(result, indent=1))
     return result
-
-
-def operator_classes(prof, steps):
-    """Device time per step of a torch-profiler capture, grouped by what launched it."""
-    groups = {}
-    for ev in prof.key_averages():
-        name = ev.key
-        t = getattr(ev, "device_time_total", None) or getattr(ev, "cuda_time_total", 0)
-        if "pa_decode" in name:
-            key = "paged attention, generation tokens (pa_decode_*)"
-        elif "pa_prompt" in name:
-            key = "prompt attention (pa_prompt_kernel)"
-        elif "pa_token" in name:
-            key = "reshape_and_cache"
-        elif "rms_norm" in name or "rotary" in name or "silu" in name:
-            key = "rms_norm / rotary / silu_and_mul"
-        elif "Cijk" in name or "gemm" in name.lower() or "hipblas" in name.lower():
-            key = "GEMMs (hipBLASLt / rocBLAS)"
-        else:
-            key = "other (adds, embedding, sampling, copies)"
-        groups[key] = groups.get(key, 0.0) + t / steps / 1e3
-    return dict(sorted(groups.items(), key=lambda kv: -kv[1]))
 
 
 def main():
@@ -284,13 +251,9 @@ def main():
     ap.add_argument("--num-blocks", type=int, default=0)
     ap.add_argument("--dtype", default="float16")
     ap.add_argument("--json", default="")
-    ap.add_argument("--profile-steps", type=int, default=0,
-                    help="attribute device time to operator classes over this many steps (slows the run)")
-    ap.add_argument("--profile-from", type=int, default=300)
     args = ap.parse_args()
     res = run(args.model, args.num_prompts, args.seed, args.max_num_batched_tokens, args.max_num_seqs,
-              args.block_size, args.num_blocks, args.dtype, profile_steps=args.profile_steps,
-              profile_from=args.profile_from)
+              args.block_size, args.num_blocks, args.dtype)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(res, f, indent=1)
