@@ -368,20 +368,24 @@ def test_decode_randomized_shapes_against_oracle(pkg, seed):
         helpers.assert_close(got, ref, atol, 2 * rtol, f"seed {seed} S={S} H={H} D={D} B={B} {dtype} split={split}")
 
 
-def test_decode_item_list_plan_leaves_near_uniform_batches_unsplit(pkg):
-    """Item-list mode decides on the device whether partitions pay: a batch
-    whose longest context is within a quarter of the mean keeps one workgroup
-    per row (no listed pairs, partition length 'infinite'), a mixed batch on the
-    same workspace right after it is split.  The plan sits in the last three
-    words of the workspace.  Both results must match the oracle."""
+def test_decode_item_list_plan_splits_only_rows_that_would_hold_up_the_launch(pkg):
+    """Item-list mode decides on the device whether partitions pay: they do
+    when the longest sequence exceeds half the average work per resident
+    workgroup slot (blocks x heads / slots; 512 slots for head size 64).  A
+    batch of 160 equal-length sequences keeps one workgroup per row (no listed
+    pairs, partition length 'infinite'); the same workspace then serves a
+    mixed batch, which is split, and a batch of 40 equal-length sequences, too
+    few rows to fill the slots, which is split as well.  The plan sits in the
+    last three words of the workspace.  All results must match the oracle."""
     import torch
     H, D, B = 8, 64, 16
-    uniform = [1400 + (13 * i) % 120 for i in range(40)]
-    mixed = [3000 if i % 7 == 0 else 150 + i for i in range(40)]
-    nbytes = pkg._capi.decode_workspace_bytes(40, H, D, B, 3000)
-    assert nbytes > 0 and nbytes >= pkg._capi.decode_workspace_bytes(40, H, D, B, max(uniform))
-    ws = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda:0")
-    for name, ctx, split_expected in (("uniform", uniform, False), ("mixed", mixed, True), ("uniform again", uniform, False)):
+    uniform = [1400 + (13 * i) % 120 for i in range(160)]
+    mixed = [3000 if i % 17 == 0 else 150 + i for i in range(160)]
+    few = uniform[:40]
+    nbytes = max(pkg._capi.decode_workspace_bytes(len(c), H, D, B, max(c)) for c in (uniform, mixed, few))
+    ws = torch.zeros(nbytes // 4 + 2, dtype=torch.float32, device="cuda:0")
+    for name, ctx, split_expected in (("uniform", uniform, False), ("mixed", mixed, True), ("few rows", few, True),
+                                      ("uniform again", uniform, False)):
         case = datagen.DecodeCase(name="plan", dtype="float16", num_seqs=len(ctx), num_heads=H, head_size=D, block_size=B,
                                   num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
                                   tables="permutation", seed=91)
@@ -389,6 +393,7 @@ def test_decode_item_list_plan_leaves_near_uniform_batches_unsplit(pkg):
         qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
         out = torch.full((len(ctx), H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
         need = pkg._capi.decode_workspace_bytes(len(ctx), H, D, B, inp["max_context_len"])
+        assert need % 4 == 0
         view = ws[:need // 4]
         pkg._capi.single_query_cached_kv_attention_ws(out, query, kc, vc, inp["scale"], bt, cl, B,
                                                       inp["max_context_len"], view)
@@ -398,6 +403,7 @@ def test_decode_item_list_plan_leaves_near_uniform_batches_unsplit(pkg):
             bpp = plan[2]
             assert bpp * B >= 1024 and bpp < (1 << 24), name
             assert plan[1] == sum(min((c + bpp * B - 1) // (bpp * B), 4) - 1 for c in ctx), name
+            assert plan[1] > 0, name
         else:
             assert plan[1] == 0 and plan[2] == 1 << 24, name
         ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(

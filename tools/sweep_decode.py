@@ -52,6 +52,9 @@ def configs():
     add("ns_outlier_8k", ragged="outlier", ctx=8192)
     add("ns_outlier_2k_bs64", ragged="outlier", ctx=2048, S=64)
     add("ns_bs64_ctx2048", ctx=2048, S=64)
+    add("ns_bs32_ctx2048", ctx=2048, S=32)
+    add("ns_bs16_ctx4096", ctx=4096, S=16)
+    add("ns_bs40_ctx4096", ctx=4096, S=40)
     add("ns_bs32_ragged2048", ctx=2048, S=32, ragged=True)
     add("ns_bs64_ragged2048", ctx=2048, S=64, ragged=True)
     add("ns_bs256_ragged2048", ctx=2048, S=256, ragged=True)

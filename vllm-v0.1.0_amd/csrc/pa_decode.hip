@@ -629,12 +629,15 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 // Plans one launch from context_lens: one workgroup of kPlanThreads.
 //
 // 1. (item-list form) Whether to split at all.  Partitions exist to keep one
-//    long sequence from setting the launch time alone; when the longest
-//    sequence is within uniform_pct percent of the mean, rows end together
-//    anyway and the second workgroup per row, the workspace round trip and the
-//    merge only cost (3-4 % at 256 sequences of exactly 2048 or 4096 tokens).
-//    The partition length in force goes to counters[2] for the decode and
-//    merge kernels: the planned one, or kNoSplitBlocks.
+//    long sequence from setting the launch time alone.  A row workgroup shares
+//    the GPU with resident_slots - 1 others, so the longest row, which starts
+//    first, ends in time as long as it is no longer than the average work per
+//    slot, blocks * heads / resident_slots; splitting then only adds a second
+//    workgroup per row, the workspace round trip and the merge (3-4 % at 256
+//    sequences of up to 2048 tokens).  The rule: split when the longest
+//    sequence exceeds split_pct percent of that average.  The partition length
+//    in force goes to counters[2] for the decode and merge kernels: the planned
+//    one, or kNoSplitBlocks.
 // 2. (item-list form) The list of (sequence, partition >= 1) pairs.  A
 //    sequence has ceil(blocks / blocks_per_part) partitions, at most max_parts
 //    (the last partition then runs to the end of the context).
@@ -657,7 +660,9 @@ struct PlanArgs {
   int block_size;
   int blocks_per_part;  // planned partition length (item-list form)
   int max_parts;        // 1 = no item list
-  int uniform_pct;
+  int split_pct;
+  int num_heads;
+  int resident_slots;   // workgroups of the decode kernel the GPU holds at a time
   uint32_t* items;
   unsigned* counters;
   int2* row_table;      // null = no balanced order
@@ -707,9 +712,9 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
       }
       __syncthreads();
     }
-    const bool uniform =
-        (unsigned long long)scan[0] * 100ull * (unsigned)num_seqs <= sums[0] * (unsigned long long)p.uniform_pct;
-    bpp = uniform ? kNoSplitBlocks : p.blocks_per_part;
+    const bool fits = (unsigned long long)scan[0] * 100ull * (unsigned)p.resident_slots <=
+                      sums[0] * (unsigned long long)p.num_heads * (unsigned long long)p.split_pct;
+    bpp = fits ? kNoSplitBlocks : p.blocks_per_part;
     __syncthreads();
     for (int s0 = 0; s0 < num_seqs; s0 += nthreads) {
       const int seq = s0 + tid;
@@ -884,7 +889,7 @@ constexpr int kPlainOrderRows = 2048;
 constexpr int kPlanPerCall = 0;  // this call, for itself
 constexpr int kPlanShared = 1;   // this call, for itself and later calls on the same context_lens
 constexpr int kPlanReady = 2;    // an earlier call did
-constexpr int kListUniformPct = 125;  // kModeList: no partitions while the longest context <= 1.25 x the mean
+constexpr int kListSplitPct = 50;  // kModeList: partitions when the longest row exceeds half the average work per slot
 
 // Waves per workgroup: 4, except head size 64, whose rows stream a quarter of
 // the bytes of a head-size-128 row against the same fixed cost and whose 91
@@ -906,9 +911,9 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
   const unsigned row_wgs = a.row_table != nullptr ? 8u * (unsigned)a.slots_per_xcd * (unsigned)a.num_heads : rows;
   const bool list = a.num_parts > 1 && a.items != nullptr;
   if ((list || a.row_table != nullptr) && !plan_ready) {
-    static const int uniform_pct = [] {
-      const char* e = getenv("PA_DECODE_LIST_UNIFORM_PCT");  // tuning aid only: 0 = always split
-      return e ? atoi(e) : kListUniformPct;
+    static const int split_pct = [] {
+      const char* e = getenv("PA_DECODE_SPLIT_PCT");  // tuning aid only: 0 = always split
+      return e ? atoi(e) : kListSplitPct;
     }();
     PlanArgs p;
     p.context_lens = a.context_lens;
@@ -916,7 +921,9 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
     p.block_size = B;
     p.blocks_per_part = a.blocks_per_part;
     p.max_parts = list ? a.num_parts : 1;
-    p.uniform_pct = uniform_pct;
+    p.split_pct = split_pct;
+    p.num_heads = a.num_heads;
+    p.resident_slots = 256 * (NW == 4 ? 3 : 2);  // 256 CUs x workgroups per CU at this kernel's register count
     p.items = const_cast<uint32_t*>(a.items);
     p.counters = a.counters;
     p.row_table = const_cast<int2*>(a.row_table);
