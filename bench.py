@@ -262,7 +262,7 @@ def main(argv=None):
             cache_ops.reshape_and_cache(key, value, key_caches[l], value_caches[l], slot_mapping)
             attention_ops.single_query_cached_kv_attention_planned(
                 out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
-                workspace, l > 0)
+                workspace, l > 0, S * CTX)
 
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     units = dist.sum_float(float(S * args.steps), device)
@@ -279,7 +279,7 @@ def main(argv=None):
             e0.record()
             attention_ops.single_query_cached_kv_attention_planned(
                 out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
-                workspace, True)  # the plan of the timed steps above is still in the workspace
+                workspace, True, S * CTX)  # the plan of the timed steps above is still in the workspace
             e1.record()
         torch.cuda.synchronize()
         times_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)

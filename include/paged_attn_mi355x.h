@@ -131,7 +131,12 @@ int pa_single_query_cached_kv_attention_ws(
  * that was never made, or made for other arguments, gives wrong results (but
  * no out-of-range access).  pa_single_query_cached_kv_attention_ws makes the
  * plan on every call, and makes the row order only for launches big enough to
- * win it back.  No counterpart in the reference.
+ * win it back.  total_context_len is the sum of context_lens if the caller
+ * knows it on the host (the engine builds context_lens from a host list), else
+ * -1: with it the library can tell on the host that no sequence of a big batch
+ * is long enough to need partitions, and leaves that machinery out of the
+ * launch.  It must be the same for all calls on one plan.  No counterpart in
+ * the reference.
  */
 int pa_single_query_cached_kv_attention_planned(
     void* out, const void* query, const void* key_cache, const void* value_cache,
@@ -139,7 +144,7 @@ int pa_single_query_cached_kv_attention_planned(
     int num_seqs, int num_heads, int head_size, int block_size,
     int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
     int dtype, void* workspace, size_t workspace_bytes, int plan_ready,
-    void* stream);
+    int64_t total_context_len, void* stream);
 
 /*
  * Scatter new key/value vectors into the paged caches.

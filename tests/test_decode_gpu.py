@@ -449,3 +449,36 @@ def test_decode_plan_shared_by_several_calls(pkg, longest, entry):
             inp["context_lens"], case.dtype), case.dtype)
         atol, rtol = helpers.TIGHT[case.dtype]
         helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"{entry} layer {layer}")
+
+
+def test_decode_total_context_hint_leaves_the_item_list_out(pkg):
+    """With the sum of the context lengths known on the host, a big batch whose
+    longest context cannot hold up the launch is run as plain rows (in the
+    balanced order): no item list is planned — the counters at the end of the
+    workspace stay untouched — and the result is the oracle's.  Without the
+    hint the same call plans the list on the device (and lists nothing)."""
+    import torch
+    S, H, D, B = 300, 8, 64, 16
+    ctx = [1100 + (37 * i) % 200 for i in range(S)]
+    case = datagen.DecodeCase(name="hint", dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                              num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                              tables="permutation", seed=93)
+    inp = datagen.make_decode_inputs(case)
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+    ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype), case.dtype)
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, max(ctx))
+    assert nbytes > 8 * 8 * S  # more than a row table: the list form is planned for
+    atol, rtol = helpers.TIGHT[case.dtype]
+    for total, counters_written in ((sum(ctx), False), (-1, True)):
+        ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda:0")
+        for ready in (False, True):
+            out = torch.full((S, H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, max(ctx), ws,
+                                                               ready, total)
+            torch.cuda.synchronize()
+            helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"total={total} ready={ready}")
+        assert bool(torch.isnan(ws[-3:]).all()) != counters_written
+        if counters_written:
+            assert ws.view(torch.int32)[-3:].tolist()[1:] == [0, 1 << 24]

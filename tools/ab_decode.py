@@ -52,7 +52,7 @@ def load(name):
     lib.pa_last_error.restype = ctypes.c_char_p
     if hasattr(lib, "pa_single_query_cached_kv_attention_planned"):
         lib.pa_single_query_cached_kv_attention_planned.argtypes = [
-            vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, vp]
+            vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, i64, vp]
         lib.pa_single_query_cached_kv_attention_planned.restype = i32
         lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
         lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
@@ -109,7 +109,7 @@ def main():
                 wss[n] = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
                 rc = libs[n].pa_single_query_cached_kv_attention_planned(
                     out.data_ptr(), q.data_ptr(), kcs[0].data_ptr(), vcs[0].data_ptr(), 1.0 / D ** 0.5, bt.data_ptr(),
-                    cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1, wss[n].data_ptr(), nb, 0, stream)
+                    cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1, wss[n].data_ptr(), nb, 0, sum(ctxs), stream)
                 assert rc == 0, libs[n].pa_last_error()
 
         def call(lib, i):
@@ -118,7 +118,7 @@ def main():
                 rc = lib.pa_single_query_cached_kv_attention_planned(
                     out.data_ptr(), q.data_ptr(), kcs[i % copies].data_ptr(), vcs[i % copies].data_ptr(),
                     1.0 / D ** 0.5, bt.data_ptr(), cl.data_ptr(), S, H, D, B, bps, ctx, q.stride(0), 1,
-                    wss[n].data_ptr(), wss[n].numel(), 1, stream)
+                    wss[n].data_ptr(), wss[n].numel(), 1, sum(ctxs), stream)
                 assert rc == 0, lib.pa_last_error()
                 return
             rc = lib.pa_single_query_cached_kv_attention(

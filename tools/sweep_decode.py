@@ -124,10 +124,11 @@ def run(cfg, pkg, device, launches=30):
     if PLANNED:
         ws = torch.empty(pkg.attention_ops.decode_workspace_bytes(S, H, D, B, ctx), dtype=torch.uint8, device=device)
         planned = pkg.attention_ops.single_query_cached_kv_attention_planned
-        planned(out, q, kcs[0], vcs[0], scale, bt, cl, B, ctx, ws, False)
+        total = -1 if os.environ.get("SWEEP_NO_HINT") else sum(ctxs)  # the host-side sum of context_lens
+        planned(out, q, kcs[0], vcs[0], scale, bt, cl, B, ctx, ws, False, total)
 
         def op(out, q, kc, vc, scale, bt, cl, B, ctx):  # noqa: F811
-            planned(out, q, kc, vc, scale, bt, cl, B, ctx, ws, True)
+            planned(out, q, kc, vc, scale, bt, cl, B, ctx, ws, True, total)
     for i in range(3):
         op(out, q, kcs[i % copies], vcs[i % copies], scale, bt, cl, B, ctx)
     torch.cuda.synchronize()

@@ -69,7 +69,7 @@ def _load() -> ctypes.CDLL:
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, vp]
     lib.pa_single_query_cached_kv_attention_ws.restype = i32
     lib.pa_single_query_cached_kv_attention_planned.argtypes = [
-        vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, vp]
+        vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, i64, vp]
     lib.pa_single_query_cached_kv_attention_planned.restype = i32
     lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
@@ -156,7 +156,7 @@ def single_query_cached_kv_attention_ws(out, query, key_cache, value_cache, scal
 
 def single_query_cached_kv_attention_planned(out, query, key_cache, value_cache, scale, block_tables,
                                              context_lens, block_size, max_context_len, workspace,
-                                             plan_ready, stream=None) -> None:
+                                             plan_ready, total_context_len=-1, stream=None) -> None:
     """One workspace for all calls on the same context_lens: plan_ready False on the first, True after."""
     S, H, D = query.shape
     ws_ptr = workspace.data_ptr() if workspace is not None else None
@@ -165,7 +165,7 @@ def single_query_cached_kv_attention_planned(out, query, key_cache, value_cache,
         out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), float(scale),
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
         max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
-        1 if plan_ready else 0, _stream_handle(stream))
+        1 if plan_ready else 0, int(total_context_len), _stream_handle(stream))
     check(rc)
 
 

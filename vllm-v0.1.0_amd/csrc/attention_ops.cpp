@@ -74,6 +74,7 @@ void single_query_cached_kv_attention(
 // decode_workspace_bytes, a uint8 tensor on the GPU), the first layer passes
 // plan_ready = false and the launch plan is made into it, the others pass
 // true and reuse it.  An empty workspace (size 0) is allowed when none is needed.
+// total_context_len: the sum of context_lens if known on the host, else -1.
 int64_t decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size, int max_context_len) {
   return static_cast<int64_t>(pa_decode_workspace_bytes(num_seqs, num_heads, head_size, block_size, max_context_len));
 }
@@ -81,7 +82,7 @@ int64_t decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int b
 void single_query_cached_kv_attention_planned(
     torch::Tensor& out, torch::Tensor& query, torch::Tensor& key_cache, torch::Tensor& value_cache, float scale,
     torch::Tensor& block_tables, torch::Tensor& context_lens, int block_size, int max_context_len,
-    torch::Tensor& workspace, bool plan_ready) {
+    torch::Tensor& workspace, bool plan_ready, int64_t total_context_len) {
   using namespace pa_shim;
   const char* what = "single_query_cached_kv_attention_planned";
   const DecodeShape sh = check_decode_args(what, out, query, key_cache, value_cache, block_tables, context_lens, block_size);
@@ -94,7 +95,7 @@ void single_query_cached_kv_attention_planned(
                    block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs, sh.num_heads, sh.head_size,
                    block_size, static_cast<int>(block_tables.size(1)), max_context_len,
                    sh.num_seqs > 0 ? query.stride(0) : 0, sh.dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr,
-                   ws_bytes, plan_ready ? 1 : 0, current_stream(query)),
+                   ws_bytes, plan_ready ? 1 : 0, total_context_len, current_stream(query)),
                what);
 }
 

@@ -903,6 +903,19 @@ constexpr int kListSplitPct = 50;  // kModeList: partitions when the longest row
 #define PA_DECODE_NW_HEAD64_MAXD 64
 #endif
 
+static int split_pct() {
+  static const int pct = [] {
+    const char* e = getenv("PA_DECODE_SPLIT_PCT");  // tuning aid only: 0 = always split
+    return e ? atoi(e) : kListSplitPct;
+  }();
+  return pct;
+}
+
+// workgroups of the decode kernel the GPU holds at a time: 256 CUs x workgroups per CU at the kernel's register count
+static int resident_slots(int head_size) {
+  return 256 * (head_size <= PA_DECODE_NW_HEAD64_MAXD && PA_DECODE_NW_HEAD64 == 8 ? 2 : 3);
+}
+
 template <typename E, int D, int B>
 static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hipStream_t stream) {
   constexpr int NW = D <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves;
@@ -911,19 +924,15 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
   const unsigned row_wgs = a.row_table != nullptr ? 8u * (unsigned)a.slots_per_xcd * (unsigned)a.num_heads : rows;
   const bool list = a.num_parts > 1 && a.items != nullptr;
   if ((list || a.row_table != nullptr) && !plan_ready) {
-    static const int split_pct = [] {
-      const char* e = getenv("PA_DECODE_SPLIT_PCT");  // tuning aid only: 0 = always split
-      return e ? atoi(e) : kListSplitPct;
-    }();
     PlanArgs p;
     p.context_lens = a.context_lens;
     p.num_seqs = a.num_seqs;
     p.block_size = B;
     p.blocks_per_part = a.blocks_per_part;
     p.max_parts = list ? a.num_parts : 1;
-    p.split_pct = split_pct;
+    p.split_pct = split_pct();
     p.num_heads = a.num_heads;
-    p.resident_slots = 256 * (NW == 4 ? 3 : 2);  // 256 CUs x workgroups per CU at this kernel's register count
+    p.resident_slots = resident_slots(D);
     p.items = const_cast<uint32_t*>(a.items);
     p.counters = a.counters;
     p.row_table = const_cast<int2*>(a.row_table);
@@ -1080,7 +1089,7 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
                         const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads,
                         int head_size, int block_size, int max_num_blocks_per_seq, int max_context_len,
                         int64_t q_stride, int dtype, void* workspace, size_t workspace_bytes, int plan_mode,
-                        void* stream) {
+                        int64_t total_context_len, void* stream) {
   clear_error();
   PA_REQUIRE(num_seqs >= 0 && num_heads >= 0, "negative num_seqs (%d) or num_heads (%d)", num_seqs, num_heads);
   if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
@@ -1132,6 +1141,19 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
+    if (p.list && total_context_len >= 0) {
+      // The plan kernel's rule, applied here with what the caller knows: no sequence is
+      // longer than max_context_len, and the batch holds at least total / block_size blocks.
+      // If even so the longest row cannot hold up the launch, the item list, its workgroup
+      // slots and the merge launch are left out altogether.
+      const int64_t longest = (max_context_len + block_size - 1) / block_size;
+      const int64_t blocks = total_context_len / block_size;
+      if (longest * 100 * resident_slots(head_size) <= blocks * num_heads * split_pct()) {
+        p.num_parts = 1;
+        p.list = false;
+        p.blocks_per_part = longest > 0 ? (int)longest : 1;
+      }
+    }
     if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) p.slots_per_xcd = 0;  // the table holds 8-byte entries
     if (rows * p.num_parts >= (1ll << 31)) p = PartitionPlan{1, p.blocks_per_part, false};
     if (workspace_bytes_for(rows, p, head_size, num_seqs) > workspace_bytes) p.slots_per_xcd = 0;  // retry without the table
@@ -1181,7 +1203,7 @@ extern "C" int pa_single_query_cached_kv_attention(
     int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* stream) {
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, nullptr, 0,
-                          pa::kPlanPerCall, stream);
+                          pa::kPlanPerCall, -1, stream);
 }
 
 extern "C" size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size,
@@ -1198,15 +1220,15 @@ extern "C" int pa_single_query_cached_kv_attention_ws(
     size_t workspace_bytes, void* stream) {
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
-                          workspace_bytes, pa::kPlanPerCall, stream);
+                          workspace_bytes, pa::kPlanPerCall, -1, stream);
 }
 
 extern "C" int pa_single_query_cached_kv_attention_planned(
     void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
     const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
     int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* workspace,
-    size_t workspace_bytes, int plan_ready, void* stream) {
+    size_t workspace_bytes, int plan_ready, int64_t total_context_len, void* stream) {
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
-                          workspace_bytes, plan_ready ? pa::kPlanReady : pa::kPlanShared, stream);
+                          workspace_bytes, plan_ready ? pa::kPlanReady : pa::kPlanShared, total_context_len, stream);
 }

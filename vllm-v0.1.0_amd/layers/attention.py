@@ -85,7 +85,8 @@ class PagedAttention(nn.Module):
             cached = (key, torch.empty(nbytes, dtype=torch.uint8, device=query.device))
             input_metadata._decode_workspace = cached
         planned(output, query, key_cache, value_cache, self.scale, input_metadata.block_tables,
-                input_metadata.context_lens, block_size, input_metadata.max_context_len, cached[1], plan_ready)
+                input_metadata.context_lens, block_size, input_metadata.max_context_len, cached[1], plan_ready,
+                int(getattr(input_metadata, "total_context_len", -1)))
 
     def forward(
         self,

@@ -150,4 +150,6 @@ def prepare_inputs(
     )
     # keep the staging buffer alive until the copy has been consumed
     meta._staging = host
+    # known here on the host, and useful to the attention operator's launch plan
+    meta.total_context_len = int(ctx.sum()) if num_gen else 0
     return tokens_t, positions_t, meta
