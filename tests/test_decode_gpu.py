@@ -482,3 +482,59 @@ def test_decode_total_context_hint_leaves_the_item_list_out(pkg):
         assert bool(torch.isnan(ws[-3:]).all()) != counters_written
         if counters_written:
             assert ws.view(torch.int32)[-3:].tolist()[1:] == [0, 1 << 24]
+
+
+def test_decode_step_replays_from_a_hip_graph(pkg):
+    """A decode step of three layers (reshape_and_cache, then attention with the
+    plan shared by the layers; and the module function with the reference's
+    signature, which takes its scratch from torch's allocator) captured into a
+    HIP graph and replayed with new queries: same results as eager launches."""
+    import torch
+    dev = "cuda:0"
+    S, H, D, B, L = 70, 8, 64, 16, 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    ctx = torch.randint(1, 1500, (S,), generator=g, device=dev, dtype=torch.int32)
+    ctx[5] = 2300
+    max_ctx = int(ctx.max())
+    bps = (max_ctx + B - 1) // B
+    NB = S * bps
+    bt = torch.randperm(NB, generator=g, device=dev).to(torch.int32).reshape(S, bps)
+    slots = (bt[torch.arange(S, device=dev), ((ctx - 1) // B).long()].long() * B + ((ctx - 1) % B).long()).to(torch.int32)
+    kcs = [torch.randn(NB, H, D // 8, B, 8, dtype=torch.float16, device=dev, generator=g) for _ in range(L)]
+    vcs = [torch.randn(NB, H, D, B, dtype=torch.float16, device=dev, generator=g) for _ in range(L)]
+    qkv = torch.randn(S, 3, H, D, dtype=torch.float16, device=dev, generator=g)
+    outs = [torch.zeros(S, H, D, dtype=torch.float16, device=dev) for _ in range(2 * L)]
+    ws = torch.empty(pkg.attention_ops.decode_workspace_bytes(S, H, D, B, max_ctx), dtype=torch.uint8, device=dev)
+    total = int(ctx.sum())
+
+    def step():
+        for l in range(L):
+            pkg.cache_ops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kcs[l], vcs[l], slots)
+            pkg.attention_ops.single_query_cached_kv_attention_planned(
+                outs[l], qkv[:, 0], kcs[l], vcs[l], D ** -0.5, bt, ctx, B, max_ctx, ws, l > 0, total)
+            pkg.attention_ops.single_query_cached_kv_attention(
+                outs[L + l], qkv[:, 0], kcs[l], vcs[l], D ** -0.5, bt, ctx, B, max_ctx)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()  # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for trial in range(2):
+        qkv.copy_(torch.randn(S, 3, H, D, dtype=torch.float16, device=dev, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [o.clone() for o in outs]
+        caches = [c.clone() for c in kcs + vcs]
+        step()
+        torch.cuda.synchronize()
+        for a, b in zip(replayed, outs):
+            assert torch.equal(a, b), trial
+        for a, b in zip(caches, kcs + vcs):
+            assert torch.equal(a, b), trial
+        for l in range(L):  # the two entry points agree up to the summation order of their launch forms
+            assert torch.allclose(outs[l].float(), outs[L + l].float(), atol=2e-3, rtol=2e-3)
