@@ -6,7 +6,7 @@ set -euo pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()"
-python -u bench.py                                  | tee gpurun_out/bench.json            # profiles/r01k_bench.json
+python -u bench.py                                  | tee gpurun_out/bench.json            # profiles/r01p_bench.json
 python -u tools/sweep_decode.py --graph             | tee gpurun_out/sweep_decode.log      # profiles/r01g_decode_sweep.txt
 python -u tools/read_bw.py --build && python -u tools/read_bw.py | tee gpurun_out/read_bw.log   # profiles/r01j_hbm_read_ceiling.txt
 python -u tools/bench_cache_ops.py                  | tee gpurun_out/bench_cache.log       # profiles/r01f_cache_ops_bench.txt
@@ -15,6 +15,13 @@ python -u tools/bench_elementwise.py                | tee gpurun_out/bench_eleme
 python -u tools/bench_prompt.py                     | tee gpurun_out/bench_prompt.log      # profiles/r01e_prompt_attention_bench.txt
 python -u tools/bench_decoder_step.py               | tee gpurun_out/decoder_step.log      # profiles/r01h_decoder_step.txt
 python -u tools/exp_step.py                         | tee gpurun_out/exp_step.log          # reshape_and_cache -> decode interaction
+python -u tools/exp_ragged_balance.py               | tee gpurun_out/exp_balance.log       # XCD imbalance of ragged batches (add --lognormal)
+for m in "PA_DECODE_BALANCE=0" "PA_DECODE_BALANCE=4" "X=1 --planned"; do                   # profiles/r01n_decode_balance.txt
+  set -- $m; env $1 python -u tools/sweep_decode.py ${2:-} | tee -a gpurun_out/decode_balance.log
+done
+python -u tools/bench_throughput.py --json gpurun_out/throughput_7b.json                   # profiles/r01m_throughput_llama7b.json
+#   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_tp -o tp -- python3 tools/bench_throughput.py
+#   python tools/summarize_kernel_classes.py /tmp/prof_tp/tp_kernel_stats.csv 2326          # profiles/r01m_throughput_kernel_classes.txt
 # rocprofv3 passes (kernel trace, then FETCH_SIZE and WRITE_SIZE each in a run of its own):
 #   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
 #   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
