@@ -127,9 +127,10 @@ int pa_single_query_cached_kv_attention_ws(
  * The first call of a step passes plan_ready = 0 and makes the plan; the
  * others pass plan_ready = 1 with the SAME workspace, num_seqs, num_heads,
  * head_size, block_size, max_context_len and an unchanged context_lens, and
- * skip that kernel.  The rest of the workspace is scratch as above.  A plan
- * that was never made, or made for other arguments, gives wrong results (but
- * no out-of-range access).  pa_single_query_cached_kv_attention_ws makes the
+ * skip that kernel.  The rest of the workspace is scratch as above.  The plan
+ * carries a stamp of the sizes it was made for: with a workspace whose plan
+ * was never made, or made for other sizes, the call writes nothing at all.  A
+ * plan made from other context_lens of the same sizes gives wrong results.  pa_single_query_cached_kv_attention_ws makes the
  * plan on every call, and makes the row order only for launches big enough to
  * win it back.  total_context_len is the sum of context_lens if the caller
  * knows it on the host (the engine builds context_lens from a host list), else

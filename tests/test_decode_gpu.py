@@ -55,8 +55,8 @@ def test_decode_matches_reference_fixture(pkg, name, split):
 def test_partition_plan_splits_small_batches_only(pkg):
     c = pkg._capi
     # 256 x 32 rows fill the chip on their own: no partitions, only the row table of the
-    # balanced order (8 XCDs x 32 sequences x 8 bytes)
-    assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == 8 * 32 * 8
+    # balanced order (8 XCDs x 32 sequences x 8 bytes, and a stamp)
+    assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == (8 * 32 + 1) * 8
     # too few sequences to balance, contexts too short to split
     assert c.decode_workspace_bytes(40, 32, 128, 16, 1024) == 0
     # one sequence: 32 rows -> split into partitions of at least 64 tokens / 4 blocks
@@ -538,3 +538,42 @@ def test_decode_step_replays_from_a_hip_graph(pkg):
             assert torch.equal(a, b), trial
         for l in range(L):  # the two entry points agree up to the summation order of their launch forms
             assert torch.allclose(outs[l].float(), outs[L + l].float(), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("longest", [300, 2600], ids=["rows", "item_list"])
+def test_decode_with_a_workspace_that_holds_no_plan_writes_nothing(pkg, longest):
+    """plan_ready=True on a workspace whose plan was never made (arbitrary
+    bytes), or was made for another batch size: every workgroup sees that the
+    stamp does not match and leaves; `out` keeps its contents.  The same
+    workspace then serves a proper pair of calls."""
+    import torch
+    rng = np.random.default_rng(8)
+    H, D, B = 8, 64, 16
+    results = {}
+    ws = None
+    for S in (100, 96):
+        ctx = [int(c) for c in rng.integers(1, longest + 1, size=S)]
+        ctx[3] = longest
+        case = datagen.DecodeCase(name="noplan", dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                                  num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                  tables="permutation", seed=600 + S)
+        inp = datagen.make_decode_inputs(case)
+        qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+        nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
+        if ws is None:  # S = 100: arbitrary bytes;  S = 96: the plan of the S = 100 batch
+            ws = torch.randint(0, 2 ** 31 - 1, (nbytes // 4 + 64,), dtype=torch.int32, device="cuda:0")
+        out = torch.full((S, H, D), 7.0, dtype=qkv.dtype, device="cuda:0")
+        pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
+                                                           ws[:nbytes // 4], True)
+        torch.cuda.synchronize()
+        assert bool((out == 7.0).all()), f"S={S}: a call without a valid plan wrote to out"
+        ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+            inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+            inp["context_lens"], case.dtype), case.dtype)
+        atol, rtol = helpers.TIGHT[case.dtype]
+        for ready in (False, True):
+            out.fill_(float("nan"))
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
+                                                               ws[:nbytes // 4], ready)
+            torch.cuda.synchronize()
+            helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"S={S} ready={ready}")

@@ -224,6 +224,7 @@ struct DecodeArgs {
   int slots_per_xcd;      // balanced order: a multiple of group
   int unit;               // balanced order: consecutive sequences that are kept on one XCD (divides group)
   int plain_order;        // positional order with heads fastest (few rows)
+  unsigned plan_tag;      // what the plan kernel stamps on a plan made for these sizes (never 0)
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [1] number of pairs, [2] blocks per partition in force ([0] unused)
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
@@ -298,6 +299,8 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   unsigned row_id = blockIdx.x, row_count = gridDim.x;
   int part = 0;
   if (MODE == kModeList) {
+    // a workspace whose plan was never made, or made for other sizes: touch nothing
+    if (a.counters[0] != a.plan_tag) return;
     if (blockIdx.x < a.list_slots) {
       const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
       if (blockIdx.x >= n_items) return;  // unused slot: one scalar load, then gone
@@ -336,8 +339,10 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     const unsigned c = w / per_group, in = w - c * per_group;
     const unsigned hd = in / G;
     const unsigned i = c * G + (in - hd * G);
+    const int2 stamp = a.row_table[8u * (unsigned)a.slots_per_xcd];
     const int2 e = a.row_table[x * (unsigned)a.slots_per_xcd + i];
-    if ((unsigned)e.x >= (unsigned)a.num_seqs) return;  // an empty slot (-1); also keeps a stale table harmless
+    if ((unsigned)stamp.x != a.plan_tag || (unsigned)stamp.y != ~a.plan_tag) return;  // not a plan for these sizes
+    if ((unsigned)e.x >= (unsigned)a.num_seqs) return;  // an empty slot (-1)
     head = (int)hd;
     seq = e.x;
     ctx = e.y;
@@ -375,7 +380,8 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     ctx = a.context_lens[seq];
   }
 
-  const int nblk_seq = (ctx + B - 1) / B;
+  // never beyond the table's width (a plan made from other context_lens may say more)
+  const int nblk_seq = min((ctx + B - 1) / B, a.max_blocks_per_seq);
   // kModeList: a sequence that fits one partition is finished here, without the workspace
   const bool direct = !PART || (MODE == kModeList && nblk_seq <= bpp);
   const int blk_begin = PART ? part * bpp : 0;
@@ -668,6 +674,7 @@ struct PlanArgs {
   int2* row_table;      // null = no balanced order
   int unit;
   int slots_per_xcd;
+  unsigned tag;         // stamped on the item list (counters[0]) and behind the row table
 };
 
 // number of keys in [lo, lo + span) among keys[0 .. n), n a multiple of 4 (padding keys are 0 and lo > 0)
@@ -738,7 +745,7 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
       __syncthreads();
     }
     if (tid == 0) {
-      p.counters[0] = 0u;
+      p.counters[0] = p.tag;
       p.counters[1] = base;
       p.counters[2] = (unsigned)bpp;
     }
@@ -809,6 +816,7 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
     const int sq = table[i];
     p.row_table[i] = make_int2(sq, sq >= 0 ? (int)scan[sq] : 0);
   }
+  if (tid == 0) p.row_table[8 * NX] = make_int2((int)p.tag, (int)~p.tag);
 }
 
 // Combines the partitions of one (sequence, head): one wave per output row.
@@ -826,6 +834,7 @@ pa_decode_merge_kernel(const DecodeArgs a, const int planned_tokens_per_part, co
   const int seq = (int)(row / a.num_heads);
   const int ctx = a.context_lens[seq];
   // kModeList (skip_single): the partition length is the plan kernel's
+  if (skip_single && a.counters[0] != a.plan_tag) return;  // no plan for these sizes in the workspace
   const int tokens_per_part = skip_single ? (int)a.counters[2] * block_size : planned_tokens_per_part;
   const int nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
   if (skip_single && nparts <= 1) return;  // kModeList wrote this row directly
@@ -938,6 +947,7 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
     p.row_table = const_cast<int2*>(a.row_table);
     p.unit = a.unit;
     p.slots_per_xcd = a.slots_per_xcd;
+    p.tag = a.plan_tag;
     int plan_threads = 256;  // a power of two; the balanced order wants one thread per sequence
     while (plan_threads < kPlanThreads && plan_threads < a.num_seqs) plan_threads *= 2;
     hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(plan_threads), 0, stream, p);
@@ -1079,7 +1089,7 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
 // pairs [rows * parts][2], fp32; kModeList appends the item list
 // [num_seqs * parts] and the three counters.
 static size_t workspace_bytes_for(int64_t rows, const PartitionPlan& p, int head_size, int64_t num_seqs) {
-  size_t n = (size_t)8 * p.slots_per_xcd * sizeof(int2);
+  size_t n = p.slots_per_xcd > 0 ? ((size_t)8 * p.slots_per_xcd + 1) * sizeof(int2) : 0;  // + the stamp
   if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float);
   if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * p.num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
   return n;
@@ -1138,6 +1148,7 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
     return e ? atoi(e) : kPlainOrderRows;
   }();
   a.plain_order = rows <= plain_rows ? 1 : 0;
+  a.plan_tag = 0;
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
@@ -1158,6 +1169,11 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
     if (rows * p.num_parts >= (1ll << 31)) p = PartitionPlan{1, p.blocks_per_part, false};
     if (workspace_bytes_for(rows, p, head_size, num_seqs) > workspace_bytes) p.slots_per_xcd = 0;  // retry without the table
     if ((p.num_parts > 1 || p.slots_per_xcd > 0) && workspace_bytes_for(rows, p, head_size, num_seqs) <= workspace_bytes) {
+      unsigned tag = 0x9e3779b9u;  // the sizes a plan depends on, mixed into one word
+      for (unsigned v : {(unsigned)num_seqs, (unsigned)num_heads, (unsigned)block_size, (unsigned)p.num_parts,
+                         (unsigned)p.blocks_per_part, (unsigned)p.list, (unsigned)p.unit, (unsigned)p.slots_per_xcd})
+        tag = (tag ^ v) * 0x01000193u + (tag >> 15);
+      a.plan_tag = tag | 1u;
       char* base = static_cast<char*>(workspace);
       if (p.slots_per_xcd > 0) {
         // A plan made for this call alone has to earn its few microseconds: only for
@@ -1170,7 +1186,7 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
           a.unit = p.unit;
           a.group = p.group;
         }
-        base += (size_t)8 * p.slots_per_xcd * sizeof(int2);
+        base += ((size_t)8 * p.slots_per_xcd + 1) * sizeof(int2);
       }
       if (p.num_parts > 1) {
         a.num_parts = p.num_parts;
