@@ -198,7 +198,10 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //   load.  A sequence of one partition gets its output row written directly,
 //   longer ones go through the workspace and the merge kernel.  One long
 //   sequence among short ones is thereby spread over several workgroups that
-//   start first, instead of setting the launch time alone.
+//   start first, instead of setting the launch time alone.  The plan kernel
+//   may also find that no sequence needs a second partition (see there).
+// In kModeRows and kModeList the rows are walked by batch position or, given a
+// workspace, in the plan kernel's balanced order (row_table).
 constexpr int kModeRows = 0, kModeParts = 1, kModeList = 2;
 constexpr int kItemPartBits = 10;  // list items: (sequence << 10) | partition
 
@@ -220,13 +223,13 @@ struct DecodeArgs {
   int num_parts;
   int blocks_per_part;
   int group;  // sequences per work-order group (see the kernel)
-  const int2* row_table;  // balanced order: [8][slots_per_xcd] (sequence, context length), or null = positional order
+  const int2* row_table;  // balanced order: [8][slots_per_xcd] (sequence, context length), then the stamp; null = positional order
   int slots_per_xcd;      // balanced order: a multiple of group
   int unit;               // balanced order: consecutive sequences that are kept on one XCD (divides group)
   int plain_order;        // positional order with heads fastest (few rows)
   unsigned plan_tag;      // what the plan kernel stamps on a plan made for these sizes (never 0)
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
-  unsigned* counters;     // kModeList: [1] number of pairs, [2] blocks per partition in force ([0] unused)
+  unsigned* counters;     // kModeList: [0] the plan's stamp, [1] number of pairs, [2] blocks per partition in force
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
 };
 
