@@ -371,3 +371,46 @@ def test_swap_blocks_many_scattered_blocks(pkg, pinned):
     side.synchronize()
     before[back] = cpu[dst].to(DEV)
     assert torch.equal(gpu, before)
+
+
+@pytest.mark.parametrize("dtype,H,D,B", [("float16", 32, 128, 16), ("bfloat16", 5, 80, 8), ("float32", 3, 64, 32),
+                                         ("float16", 12, 64, 32)])
+def test_reshape_and_cache_decode_batches_rewrite_whole_value_tiles_safely(pkg, dtype, H, D, B):
+    """Decode-sized batches (16..511 tokens) rewrite the whole value tile of a
+    token's block — unless another token of the batch goes to the same block,
+    in which case elements are stored.  A batch with both kinds, padding rows
+    (slot -1) and a cache full of other data: the result must equal the oracle's
+    bit for bit, i.e. nothing but the addressed slots may change."""
+    import torch
+    rng = np.random.default_rng(31)
+    T, NB = 200, 300
+    tdt = getattr(torch, dtype)
+    es = torch.tensor([], dtype=tdt).element_size()
+    x = 16 // es
+    blocks = rng.permutation(NB)
+    slots = []
+    for t in range(T):
+        if t < 120:
+            slots.append(int(blocks[t]) * B + int(rng.integers(0, B)))        # alone in its block
+        elif t < 180:
+            slots.append(int(blocks[120 + (t - 120) // 3]) * B + (t - 120) % 3)  # three tokens per block
+        else:
+            slots.append(-1)
+    order = rng.permutation(T)
+    slots = [slots[i] for i in order]
+    g = torch.Generator(device=DEV)
+    g.manual_seed(32)
+    qkv = torch.randn(T, 3, H, D, device=DEV, generator=g).to(tdt)
+    kc = torch.randn(NB, H, D // x, B, x, device=DEV, generator=g).to(tdt)
+    vc = torch.randn(NB, H, D, B, device=DEV, generator=g).to(tdt)
+    view = {2: torch.int16, 4: torch.int32}[es]
+    keep = [i for i, s in enumerate(slots) if s >= 0]
+    kc_ref = kc.cpu().view(view).numpy().copy()
+    vc_ref = vc.cpu().view(view).numpy().copy()
+    pa_oracle.reshape_and_cache(qkv[keep, 1].cpu().contiguous().view(view).numpy(), qkv[keep, 2].cpu().contiguous().view(view).numpy(),
+                                kc_ref, vc_ref, np.asarray([slots[i] for i in keep], dtype=np.int32),
+                                {2: "float16", 4: "float32"}[es])
+    pkg.cache_ops.reshape_and_cache(qkv[:, 1], qkv[:, 2], kc, vc, torch.tensor(slots, dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(kc.cpu().view(view).numpy(), kc_ref)
+    assert np.array_equal(vc.cpu().view(view).numpy(), vc_ref)

@@ -7,7 +7,7 @@ import torch, statistics
 import __graft_entry__
 pkg = __graft_entry__.load_package()
 dev = "cuda:0"
-S, H, D, B, CTX, L = 256, 32, 128, 16, 1024, 6
+S, H, D, B, CTX, L = int(os.environ.get("EXP_S", 256)), 32, 128, 16, int(os.environ.get("EXP_CTX", 1024)), 6
 bps = CTX // B
 NB = S * bps
 kcs = [torch.empty(NB, H, D // 8, B, 8, dtype=torch.float16, device=dev).normal_(0, .5) for _ in range(L)]

@@ -6,7 +6,7 @@ set -euo pipefail
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()"
-python -u bench.py                                  | tee gpurun_out/bench.json            # profiles/r01q_bench.json
+python -u bench.py                                  | tee gpurun_out/bench.json            # profiles/r01r_bench.json
 python -u tools/sweep_decode.py --graph             | tee gpurun_out/sweep_decode.log      # profiles/r01g_decode_sweep.txt
 python -u tools/read_bw.py --build && python -u tools/read_bw.py | tee gpurun_out/read_bw.log   # profiles/r01j_hbm_read_ceiling.txt
 python -u tools/bench_cache_ops.py                  | tee gpurun_out/bench_cache.log       # profiles/r01f_cache_ops_bench.txt

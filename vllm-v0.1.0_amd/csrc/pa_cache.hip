@@ -129,6 +129,97 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
   }
 }
 
+// ---- reshape_and_cache for decode-sized batches: whole value rows ------------------
+//
+// A decode step adds one token to the last block of every sequence.  In the
+// value cache [blk][h][d][off] that is one element in each of the block's H * D
+// rows of B elements: written as elements (the kernel above), a million 2-byte
+// stores per layer, each dirtying part of a 32-byte sector.  The caches write
+// those back as masked partial writes while the decode kernel that follows is
+// streaming, which costs it 40 us at batch 256 (676 vs 637 us).  Here the
+// workgroups of a token read the block's whole value tile (H * D rows, one
+// contiguous run of bytes), put the new elements in, and write the tile back
+// as whole 16-byte vectors with the streaming hint: twice 128 KiB per token
+// instead of 8 KiB, but as full lines that go straight to memory.
+//
+// Read-modify-write of a block is only safe if no other token of the batch
+// goes to the same block (tokens of one prompt do): every workgroup checks the
+// whole slot_mapping first and falls back to element stores otherwise, which is
+// also what a batch with a repeated slot gets.
+template <int ES>
+__global__ void __launch_bounds__(256)
+pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ value, char* __restrict__ key_cache,
+                       char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_tokens,
+                       const int num_heads, const int head_size, const int block_size,
+                       const int64_t key_stride_bytes, const int64_t value_stride_bytes) {
+  typedef typename Word<ES>::type elem_t;
+  constexpr int X = 16 / ES;
+  const int token = blockIdx.x;
+  const int slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int off = slot % block_size;
+  int clash = 0;
+  for (int t = threadIdx.x; t < num_tokens; t += blockDim.x) {
+    const int s = slot_mapping[t];
+    clash |= (t != token && s >= 0 && s / block_size == blk) ? 1 : 0;
+  }
+  clash = __syncthreads_or(clash);
+
+  const int n = num_heads * head_size;
+  const char* krow = key + (int64_t)token * key_stride_bytes;
+  const char* vrow = value + (int64_t)token * value_stride_bytes;
+  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
+  const int nvec = n / X;
+  const int ndx = head_size / X;
+  // keys: one 16-byte vector of the token row = one innermost [x] run of the key cache
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nvec; i += gridDim.y * blockDim.x) {
+    const int h = i / ndx;
+    const int dx = i - h * ndx;
+    const int64_t kc_el = cache_block + (((int64_t)h * ndx + dx) * block_size + off) * X;
+    store_cache(reinterpret_cast<u32x4*>(key_cache + kc_el * ES), *reinterpret_cast<const u32x4*>(krow + (int64_t)i * 16));
+  }
+  if (clash) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x)
+      reinterpret_cast<elem_t*>(value_cache)[cache_block + (int64_t)i * block_size + off] =
+          reinterpret_cast<const elem_t*>(vrow)[i];
+    return;
+  }
+  // values: the tile is n rows of block_size elements = n * vpr vectors; the
+  // new element of row r sits in vector `piece` of the row, at element `lane_el`
+  const int vpr = block_size / X;  // vectors per row (>= 1: checked by the host)
+  const int piece = off / X, lane_el = off % X;
+  u32x4* tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
+  const int total = n * vpr;
+  const int per = (total + gridDim.y - 1) / gridDim.y;
+  const int lo = per * blockIdx.y, hi = min(lo + per, total);
+  constexpr int U = 4;  // vectors in flight per lane
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      if (i < hi) v[u] = __builtin_nontemporal_load(tile + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      if (i >= hi) continue;
+      const int r = i / vpr;
+      if (i - r * vpr == piece) {
+        const elem_t val = reinterpret_cast<const elem_t*>(vrow)[r];
+        if (ES == 4) {
+          v[u][lane_el] = (uint32_t)val;
+        } else {
+          const int w = lane_el >> 1, sh = (lane_el & 1) * 16;
+          v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)val << sh);
+        }
+      }
+      __builtin_nontemporal_store(v[u], tile + i);
+    }
+  }
+}
+
 // ---- reshape_and_cache / gather_cached_kv for prompt-sized batches --------------
 //
 // A prompt's tokens take consecutive slots, so 16 consecutive tokens fill whole
@@ -146,6 +237,7 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
 // negative slots are skipped, exactly as in the per-token kernel.  GATHER runs
 // the same walk the other way: cache rows -> LDS -> token rows.
 constexpr int kRunTokens = 16;
+constexpr int kAppendMinTokens = 16;  // decode batches from this size on rewrite whole value tiles
 
 template <int ES, bool GATHER>
 __global__ void __launch_bounds__(256)
@@ -320,6 +412,27 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
       PA_CHECK_LAUNCH(what);
       return PA_OK;
     }
+  }
+  static const int append_rows = [] {
+    const char* e = getenv("PA_CACHE_APPEND_ROWS");  // tuning aid only: 0 = element stores for the values
+    return e ? atoi(e) : 1;
+  }();
+  if (!GATHER && append_rows != 0 && vec && num_tokens >= kAppendMinTokens && aligned16(value_cache) &&
+      (block_size * es) % 16 == 0 && (head_size * es) % 16 == 0) {
+    // ~8 workgroups per CU; a slice is at least one pass of 4 vectors per lane
+    const int tile_vecs = num_heads * head_size * (block_size / x);
+    int sl = (2048 + num_tokens - 1) / num_tokens;
+    const int most = (tile_vecs + 4 * 256 - 1) / (4 * 256);
+    if (sl > most) sl = most;
+    if (sl < 1) sl = 1;
+    if (es == 2)
+      hipLaunchKernelGGL((pa_token_append_kernel<2>), dim3(num_tokens, sl), dim3(256), 0, st, k, v, kc, vc, slot_mapping,
+                         num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es);
+    else
+      hipLaunchKernelGGL((pa_token_append_kernel<4>), dim3(num_tokens, sl), dim3(256), 0, st, k, v, kc, vc, slot_mapping,
+                         num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es);
+    PA_CHECK_LAUNCH(what);
+    return PA_OK;
   }
 #define PA_LAUNCH_TOKEN(ES, VEC)                                                                              \
   hipLaunchKernelGGL((pa_token_cache_kernel<ES, GATHER, VEC>), dim3(num_tokens, slices), dim3(threads), 0, st, k, v, \
