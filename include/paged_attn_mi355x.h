@@ -155,6 +155,13 @@ int pa_single_query_cached_kv_attention_planned(
  *   slot_mapping [num_tokens] int32; slot = block * block_size + offset.
  *                A negative slot skips the token (the reference has no such
  *                case; this keeps padded batches from writing out of bounds).
+ *
+ * For batches of 16 to 511 tokens a token that is alone in its block (every
+ * token of a decode step is) has the block's whole value tile read and written
+ * back with the new elements in place: the other slots of that block keep
+ * their bytes, but nothing else may write to the block while the call is in
+ * flight (the reference orders swaps and copies before the model's kernels:
+ * vllm/model_executor/layers/attention.py:125-126, worker/cache_engine.py).
  */
 int pa_reshape_and_cache(
     const void* key, const void* value, void* key_cache, void* value_cache,
