@@ -9,7 +9,8 @@ batch
 
   1. prompt tokens: causal self-attention per prompt, no cache read (:115-122);
   2. wait for the cache engine's swap of this layer (:125-126);
-  3. reshape_and_cache on [:num_valid_tokens] (:131-140);
+  3. reshape_and_cache on [:num_valid_tokens] (:131-140), here as one call for the
+     prompt tokens and one for the generation tokens;
   4. single_query_cached_kv_attention on the generation tokens (:142-152);
      its launch plan is shared by the layers of a step (see below).
 
@@ -120,13 +121,18 @@ class PagedAttention(nn.Module):
 
         num_valid_tokens = input_metadata.num_valid_tokens
         if num_valid_tokens > 0 and key_cache is not None and value_cache is not None:
-            self._cache_ops.reshape_and_cache(
-                key[:num_valid_tokens],
-                value[:num_valid_tokens],
-                key_cache,
-                value_cache,
-                input_metadata.slot_mapping,
-            )
+            # One call per kind of token (the reference makes one call for all, :131-140):
+            # prompts fill runs of consecutive slots, generation tokens one slot in a block
+            # of their own, and the operator picks its kernel by what a call contains.
+            for lo, hi in ((0, num_prompt_tokens), (num_prompt_tokens, num_valid_tokens)):
+                if hi > lo:
+                    self._cache_ops.reshape_and_cache(
+                        key[lo:hi],
+                        value[lo:hi],
+                        key_cache,
+                        value_cache,
+                        input_metadata.slot_mapping[lo:hi],
+                    )
 
         if input_metadata.num_generation_tokens > 0:
             assert key_cache is not None and value_cache is not None, (
