@@ -131,7 +131,7 @@ def build_model(pkg, cfg, dtype, device, block_size, num_blocks, max_position):
 
 
 def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_num_seqs=256, block_size=16,
-        num_blocks=0, dtype_name="float16", device="cuda:0", verbose=True):
+        num_blocks=0, dtype_name="float16", device="cuda:0", verbose=True, step_log_path=""):
     import torch
     import __graft_entry__
 
@@ -189,6 +189,7 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
         groups = [SimpleNamespace(request_id=str(i), is_prompt=i < len(admitted), seq_data={i: s}, sampling_params=None,
                                   block_tables={i: s.table}) for i, s in enumerate(admitted + running)]
         gen_ctx_tokens = sum(s.get_len() for s in running)  # context tokens the paged attention reads this step
+        running_before = list(running)
         t0 = time.perf_counter()
         tokens, positions, meta = prepare_inputs(groups, B, device=device)
         ends = np.cumsum([s.get_len() for s in admitted]) - 1 if admitted else np.zeros(0, dtype=np.int64)
@@ -211,13 +212,14 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
         running = still
         steps += 1
         prompt_steps += bool(admitted)
-        step_log.append((len(admitted), n_prompt_tokens, len(order) - len(admitted), time.perf_counter() - t0, gen_ctx_tokens))
+        step_log.append((len(admitted), n_prompt_tokens, len(order) - len(admitted), time.perf_counter() - t0, gen_ctx_tokens,
+                         max((s.get_len() for s in running_before), default=0)))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
 
     total_prompt = sum(p for p, _ in requests)
     total_output = sum(o for _, o in requests)
-    decode_only = [t for a, _, n, t, _ in step_log if a == 0 and n >= max_num_seqs - 8]
+    decode_only = [w[3] for w in step_log if w[0] == 0 and w[2] >= max_num_seqs - 8]
     result = {
         "benchmark": "benchmark_throughput.py restated with synthetic requests",
         "model": f"LLaMA-{model} shape, random weights, {dtype_name}",
@@ -235,6 +237,9 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
         "paged_attention_kv_bytes": int(sum(w[4] for w in step_log)) * 2 * H * D * L
                                     * torch.tensor([], dtype=dtype).element_size(),
     }
+    if step_log_path:
+        with open(step_log_path, "w") as f:  # per step: generation sequences, their context tokens, the longest context
+            json.dump([(w[2], w[4], w[5]) for w in step_log], f)
     if verbose:
         print(json.dumps(result, indent=1))
     return result
@@ -251,9 +256,10 @@ def main():
     ap.add_argument("--num-blocks", type=int, default=0)
     ap.add_argument("--dtype", default="float16")
     ap.add_argument("--json", default="")
+    ap.add_argument("--step-log", default="", help="write (sequences, context tokens, longest context) of every step here")
     args = ap.parse_args()
     res = run(args.model, args.num_prompts, args.seed, args.max_num_batched_tokens, args.max_num_seqs,
-              args.block_size, args.num_blocks, args.dtype)
+              args.block_size, args.num_blocks, args.dtype, step_log_path=args.step_log)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(res, f, indent=1)
