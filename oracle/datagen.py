@@ -137,8 +137,14 @@ class DecodeCase:
     dist: str = "uniform1e-3"
     std: float = 0.5
     # "replacement": physical blocks sampled with replacement, as the
-    # reference test does (:190-194); "permutation": all distinct
+    # reference test does (:190-194); "permutation": all distinct;
+    # "forked": groups of `fork` consecutive sequences sampled from one prompt
+    # (parallel sampling, n = fork): the group maps the SAME physical blocks for
+    # every full block of its prompt and distinct ones from there on — what the
+    # block manager's fork + copy-on-write leaves behind
+    # (vllm/core/block_manager.py:111-135)
     tables: str = "replacement"
+    fork: int = 3
     # extra zero-padded table columns beyond ceil(max_ctx / B)
     table_pad: int = 0
     # None -> 1/sqrt(head_size), as the reference test (:197)
@@ -199,6 +205,25 @@ def make_decode_inputs(case: DecodeCase) -> Dict[str, object]:
             n = (int(ctx[s]) + B - 1) // B
             tables[s, :n] = perm[pos:pos + n]
             pos += n
+    elif case.tables == "forked":
+        F = max(int(case.fork), 1)
+        perm = permutation(NB, base + 5)
+        gen = randint((S + F - 1) // F, base + 6, 1, 2 * B)  # tokens generated since the fork, per group
+        pos = 0
+        for g0 in range(0, S, F):
+            members = range(g0, min(g0 + F, S))
+            prompt_len = max(int(min(ctx[s] for s in members)) - int(gen[g0 // F]), 0)
+            shared = prompt_len // B  # full prompt blocks stay shared; a partial last one was copied on write
+            assert pos + shared <= NB, "forked tables: num_blocks too small"
+            shared_blocks = perm[pos:pos + shared]
+            pos += shared
+            for s in members:
+                n = (int(ctx[s]) + B - 1) // B
+                own = n - shared
+                assert own >= 0 and pos + own <= NB, "forked tables: num_blocks too small"
+                tables[s, :shared] = shared_blocks
+                tables[s, shared:n] = perm[pos:pos + own]
+                pos += own
     else:
         raise ValueError(case.tables)
     scale = float(case.scale) if case.scale is not None else float(1.0 / (D ** 0.5))

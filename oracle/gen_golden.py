@@ -110,12 +110,48 @@ def decode_cases() -> List[DecodeCase]:
     return cases
 
 
-def gen_decode(ref_ns: dict) -> None:
+def decode_shard_cases() -> List[DecodeCase]:
+    """Per-GPU shapes of the tensor-parallel configurations: LLaMA-13B over two
+    GPUs = 20 heads x 128 per rank, GPT-NeoX-20B over four = 16 heads x 96 per
+    rank with three samples per prompt (heads per rank:
+    /root/reference/vllm/model_executor/models/llama.py:86-89, gpt_neox.py:51-53;
+    forked block tables: /root/reference/vllm/core/block_manager.py:111-135), and
+    the 12 heads x 64 of OPT-125m."""
+    cases: List[DecodeCase] = []
+    seed = 700
+    for dtype in datagen.DTYPES:
+        for dist in ("uniform1e-3", "normal"):
+            cases.append(DecodeCase(
+                name=f"llama13b_tp2_shard_{dtype}_{dist}", dtype=dtype, num_seqs=10, num_heads=20,
+                head_size=128, block_size=16, num_blocks=160, max_context=230, dist=dist,
+                tables="permutation", seed=seed))
+            seed += 1
+            cases.append(DecodeCase(
+                name=f"neox20b_tp4_shard_n3_{dtype}_{dist}", dtype=dtype, num_seqs=12, num_heads=16,
+                head_size=96, block_size=16, num_blocks=200, max_context=400, dist=dist,
+                tables="forked", fork=3, seed=seed))
+            seed += 1
+        cases.append(DecodeCase(
+            name=f"opt125m_{dtype}", dtype=dtype, num_seqs=9, num_heads=12, head_size=64,
+            block_size=16, num_blocks=96, max_context=150, dist="normal", tables="permutation", seed=seed))
+        seed += 1
+    # forked groups with unequal lengths inside a group, a group cut short by the end of
+    # the batch, other block sizes
+    for B, D in ((8, 96), (32, 80)):
+        cases.append(DecodeCase(
+            name=f"forked_b{B}_d{D}", dtype="float16", num_seqs=8, num_heads=4, head_size=D,
+            block_size=B, num_blocks=120, context_lens=[70, 75, 66, 200, 203, 200, 9, 12],
+            dist="normal", tables="forked", fork=3, seed=seed))
+        seed += 1
+    return cases
+
+
+def gen_decode(ref_ns: dict, cases=None, stem: str = "decode_golden") -> None:
     ref_fn = ref_ns["ref_single_query_cached_kv_attention"]
     out = {}
     metas = {}
     t0 = time.time()
-    for case in decode_cases():
+    for case in (decode_cases() if cases is None else cases):
         inp = datagen.make_decode_inputs(case)
         q = datagen.storage_to_torch(inp["qkv"], case.dtype)[:, 0]
         kc = datagen.storage_to_torch(inp["key_cache"], case.dtype)
@@ -134,8 +170,8 @@ def gen_decode(ref_ns: dict) -> None:
         metas[case.name] = {"case": json.loads(case.to_json()),
                             "inputs_sha256": datagen.checksum(inp)}
         print(f"[decode] {case.name}  ({time.time() - t0:.1f}s)", flush=True)
-    np.savez_compressed(os.path.join(GOLDEN, "decode_golden.npz"), **out)
-    with open(os.path.join(GOLDEN, "decode_golden.json"), "w") as f:
+    np.savez_compressed(os.path.join(GOLDEN, stem + ".npz"), **out)
+    with open(os.path.join(GOLDEN, stem + ".json"), "w") as f:
         json.dump(metas, f, indent=1, sort_keys=True)
 
 
@@ -238,8 +274,11 @@ def main() -> None:
     torch.manual_seed(0)
     ref_ns = _load_functions(os.path.join(REF, "test_attention.py"),
                              ["ref_masked_attention", "ref_single_query_cached_kv_attention"])
-    gen_cache()
-    gen_decode(ref_ns)
+    only = sys.argv[1] if len(sys.argv) > 1 else "all"  # "all" | "shards"
+    if only == "all":
+        gen_cache()
+        gen_decode(ref_ns)
+    gen_decode(ref_ns, decode_shard_cases(), "decode_golden_shards")
 
 
 if __name__ == "__main__":

@@ -43,10 +43,16 @@ def decode_atol(inp: dict, dtype: str):
     return atol + 2.0 ** -8 * 1.05 * np.abs(mass.astype(np.float64))
 
 
-def load_decode_golden() -> Tuple[Dict[str, dict], "np.lib.npyio.NpzFile"]:
-    with open(os.path.join(GOLDEN_DIR, "decode_golden.json")) as f:
-        meta = json.load(f)
-    data = np.load(os.path.join(GOLDEN_DIR, "decode_golden.npz"), allow_pickle=False)
+def load_decode_golden() -> Tuple[Dict[str, dict], Dict[str, np.ndarray]]:
+    """The reference-generated decode fixtures: the reference test's grid and
+    edge cases (decode_golden) and the per-GPU shapes of the tensor-parallel
+    configurations, with forked block tables (decode_golden_shards)."""
+    meta, data = {}, {}
+    for stem in ("decode_golden", "decode_golden_shards"):
+        with open(os.path.join(GOLDEN_DIR, stem + ".json")) as f:
+            meta.update(json.load(f))
+        with np.load(os.path.join(GOLDEN_DIR, stem + ".npz"), allow_pickle=False) as z:
+            data.update({k: z[k] for k in z.files})
     return meta, data
 
 

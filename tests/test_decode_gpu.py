@@ -577,3 +577,151 @@ def test_decode_with_a_workspace_that_holds_no_plan_writes_nothing(pkg, longest)
                                                                ws[:nbytes // 4], ready)
             torch.cuda.synchronize()
             helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"S={S} ready={ready}")
+
+
+# ---- per-GPU shapes of the tensor-parallel configurations ---------------------
+
+def _run_entry(pkg, entry, inp, case, ws_fill=float("nan")):
+    """One decode call through the C ABI by entry-point name: "rows" (no
+    workspace), "ws" (per-call plan), "planned" (plan made, then reused by a
+    second call whose result is the one returned)."""
+    import torch
+    dev = "cuda:0"
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, dev)
+    out = torch.full((case.num_seqs, case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=dev)
+    B, mc = case.block_size, inp["max_context_len"]
+    if entry == "rows":
+        pkg._capi.single_query_cached_kv_attention(out, query, kc, vc, inp["scale"], bt, cl, B, mc)
+    else:
+        nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size, B, mc)
+        ws = torch.full((max(nbytes, 4) // 4,), ws_fill, dtype=torch.float32, device=dev) if nbytes else None
+        if entry == "ws":
+            pkg._capi.single_query_cached_kv_attention_ws(out, query, kc, vc, inp["scale"], bt, cl, B, mc, ws)
+        else:
+            total = int(np.asarray(inp["context_lens"], dtype=np.int64).sum())
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, mc, ws,
+                                                               False, total)
+            out.fill_(float("nan"))
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, mc, ws,
+                                                               True, total)
+    torch.cuda.synchronize()
+    return out
+
+
+_INPUT_CACHE = {}
+
+
+def _inputs_once(case):
+    """Inputs (and the oracle's result) of a case, generated once per process:
+    the entry-point variants of one shape share them."""
+    key = case.to_json()
+    if key not in _INPUT_CACHE:
+        _INPUT_CACHE.clear()  # one shape at a time: the caches are hundreds of megabytes
+        inp = datagen.make_decode_inputs(case)
+        _INPUT_CACHE[key] = (inp, _oracle_f32(inp, case), helpers.decode_atol(inp, case.dtype))
+    return _INPUT_CACHE[key]
+
+
+def _oracle_f32(inp, case):
+    return datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype), case.dtype)
+
+
+@pytest.mark.parametrize("entry", ["rows", "ws", "planned"])
+@pytest.mark.parametrize("dtype", datagen.DTYPES)
+def test_decode_llama13b_tp2_shard_shape(pkg, dtype, entry):
+    """LLaMA-13B over two GPUs: each rank attends 20 of the 40 heads, head size
+    128 (vllm/model_executor/models/llama.py:86-89).  64 sequences, ragged
+    contexts up to 1024 tokens, distinct physical blocks."""
+    case = datagen.DecodeCase(name="c3", dtype=dtype, num_seqs=64, num_heads=20, head_size=128, block_size=16,
+                              num_blocks=2400, max_context=1024, dist="normal", tables="permutation", seed=41)
+    inp, ref, atol = _inputs_once(case)
+    assert int(inp["context_lens"].max()) > 960 and int(inp["context_lens"].min()) < 64
+    got = helpers.out_to_f32(_run_entry(pkg, entry, inp, case), dtype)
+    helpers.assert_close(got, ref, atol, 2 * helpers.TIGHT[dtype][1], f"13B/TP2 shard {dtype} {entry}")
+
+
+@pytest.mark.parametrize("entry", ["rows", "ws", "planned"])
+@pytest.mark.parametrize("dtype", datagen.DTYPES)
+def test_decode_neox20b_tp4_shard_shape_with_forked_tables(pkg, dtype, entry):
+    """GPT-NeoX-20B over four GPUs with three samples per prompt: 16 of 64 heads
+    per rank, head size 96 (gpt_neox.py:51-53); 96 sequences = 32 groups of 3
+    that map the same physical blocks for their prompt's full blocks and
+    distinct ones after (vllm/core/block_manager.py:111-135).  Exercises the
+    per-block load policy for blocks a neighbouring sequence also maps."""
+    case = datagen.DecodeCase(name="c4", dtype=dtype, num_seqs=96, num_heads=16, head_size=96, block_size=16,
+                              num_blocks=2200, max_context=600, dist="normal", tables="forked", fork=3, seed=43)
+    inp, ref, atol = _inputs_once(case)
+    bt = inp["block_tables"]
+    shared = sum(int(bt[s, 0] == bt[s + 1, 0]) for s in range(0, 96, 3) if inp["context_lens"][s] > 48)
+    assert shared >= 20, "the forked tables share no blocks: the test would not exercise the shared-block path"
+    got = helpers.out_to_f32(_run_entry(pkg, entry, inp, case), dtype)
+    helpers.assert_close(got, ref, atol, 2 * helpers.TIGHT[dtype][1], f"NeoX-20B/TP4 shard n=3 {dtype} {entry}")
+
+
+@pytest.mark.parametrize("entry", ["rows", "planned"])
+def test_decode_forked_long_contexts_item_list(pkg, entry):
+    """Forked groups whose shared prefix crosses the 1024-token partition edge:
+    the item-list form reads shared blocks from listed partitions too."""
+    ctx = []
+    for g in range(24):
+        base = [300, 1500, 2300, 40][g % 4] + 7 * g
+        ctx += [base, base + 3, base + 1]
+    case = datagen.DecodeCase(name="c4l", dtype="float16", num_seqs=len(ctx), num_heads=8, head_size=96, block_size=16,
+                              num_blocks=sum((c + 15) // 16 for c in ctx) + 4, context_lens=ctx, dist="normal",
+                              tables="forked", fork=3, seed=47)
+    inp = datagen.make_decode_inputs(case)
+    got = helpers.out_to_f32(_run_entry(pkg, entry, inp, case), case.dtype)
+    atol, rtol = helpers.TIGHT[case.dtype]
+    helpers.assert_close(got, _oracle_f32(inp, case), atol, 2 * rtol, f"forked long {entry}")
+
+
+def test_decode_opt125m_microbench_size_properties(pkg):
+    """The microbenchmark shape at full size: 256 sequences x 12 heads x 64,
+    block 16, context 1024, fp16, distinct physical blocks.  Softmax weights sum
+    to one (V == 1), and sampled sequences equal the oracle with all 12 heads,
+    through the row form and the planned form."""
+    import torch
+    dev = "cuda:0"
+    S, H, D, B, CTX = 256, 12, 64, 16, 1024
+    nb = S * CTX // B
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    qkv = torch.randn(S, 3, H, D, dtype=torch.float16, device=dev, generator=g) * 0.5
+    query = qkv[:, 0]
+    kc = torch.randn(nb, H, D // 8, B, 8, dtype=torch.float16, device=dev, generator=g) * 0.5
+    vc = torch.ones(nb, H, D, B, dtype=torch.float16, device=dev)
+    perm = torch.randperm(nb, device=dev, generator=g).to(torch.int32).reshape(S, CTX // B)
+    ctx_list = [CTX] * S
+    ctx_list[7], ctx_list[8], ctx_list[200] = 1, CTX - 1, 513
+    cl = torch.tensor(ctx_list, dtype=torch.int32, device=dev)
+    scale = 1.0 / D ** 0.5
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, CTX)
+    ws = torch.empty(max(nbytes, 8), dtype=torch.uint8, device=dev)
+
+    def run(form, out):
+        if form == "rows":
+            pkg._capi.single_query_cached_kv_attention(out, query, kc, vc, scale, perm, cl, B, CTX)
+        else:
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, scale, perm, cl, B, CTX,
+                                                               ws if nbytes else None, False, sum(ctx_list))
+        torch.cuda.synchronize()
+
+    out = torch.empty(S, H, D, dtype=torch.float16, device=dev)
+    for form in ("rows", "planned"):
+        out.fill_(float("nan"))
+        run(form, out)
+        assert torch.allclose(out.float(), torch.ones_like(out, dtype=torch.float32), atol=1e-3), form
+    vc.copy_(torch.randn(nb, H, D, B, dtype=torch.float16, device=dev, generator=g) * 0.5)
+    for form in ("rows", "planned"):
+        out.fill_(float("nan"))
+        run(form, out)
+        for s in (0, 7, 8, 200, 255):
+            blocks = perm[s].long()
+            ref = pa_oracle.single_query_cached_kv_attention(
+                query[s:s + 1].contiguous().cpu().numpy(), kc[blocks].contiguous().cpu().numpy(),
+                vc[blocks].contiguous().cpu().numpy(), scale, np.arange(len(blocks), dtype=np.int32)[None, :],
+                np.array([ctx_list[s]], dtype=np.int32), "float16")
+            helpers.assert_close(out[s].float().cpu().numpy(), ref.astype(np.float32)[0], 2e-5, 1.5e-3,
+                                 f"microbench shape, {form}, sequence {s}")
