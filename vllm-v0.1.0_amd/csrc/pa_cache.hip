@@ -413,10 +413,7 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
       return PA_OK;
     }
   }
-  static const int append_rows = [] {
-    const char* e = getenv("PA_CACHE_APPEND_ROWS");  // tuning aid only: 0 = element stores for the values
-    return e ? atoi(e) : 1;
-  }();
+  static const int append_rows = tuning_int("PA_CACHE_APPEND_ROWS", 1);  // tuning builds: 0 = element stores for the values
   if (!GATHER && append_rows != 0 && vec && num_tokens >= kAppendMinTokens && aligned16(value_cache) &&
       (block_size * es) % 16 == 0 && (head_size * es) % 16 == 0) {
     // ~8 workgroups per CU; a slice is at least one pass of 4 vectors per lane
@@ -627,10 +624,7 @@ extern "C" int pa_swap_blocks(const void* src, void* dst, const int64_t* block_p
   char* d = static_cast<char*>(dst);
   // Many scattered blocks: one kernel launch per 256 pairs when both sides can be
   // addressed by the device and the blocks are whole 16-byte words.
-  static const int kernel_min_pairs = [] {
-    const char* e = getenv("PA_SWAP_KERNEL_MIN_PAIRS");  // tuning aid; 0 = never use the kernel
-    return e ? atoi(e) : 2;  // already at 4 blocks of 128 KiB the kernel moves 27 GB/s against 10
-  }();
+  static const int kernel_min_pairs = tuning_int("PA_SWAP_KERNEL_MIN_PAIRS", 2);  // tuning builds: 0 = never use the kernel; already at 4 blocks of 128 KiB the kernel moves 27 GB/s against 10
   if (kernel_min_pairs > 0 && num_pairs >= kernel_min_pairs && block_bytes % 16 == 0) {
     char* ds = device_alias(src);
     char* dd = device_alias(dst);

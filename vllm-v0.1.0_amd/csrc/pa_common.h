@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "paged_attn_mi355x.h"
 
@@ -31,6 +32,19 @@ void clear_error();
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int elem_size(int dtype) { return dtype == PA_DTYPE_F32 ? 4 : 2; }
+
+// A launch-form constant that a tuning build (-DPA_TUNING, the Makefile's
+// `variant` target) lets an environment variable override for A/B runs.  The
+// product build never reads the environment: its launch forms are fixed.
+inline int tuning_int(const char* env_name, int value) {
+#ifdef PA_TUNING
+  const char* e = getenv(env_name);
+  if (e != nullptr) return atoi(e);
+#else
+  (void)env_name;
+#endif
+  return value;
+}
 
 // ---- device-side vector types ---------------------------------------------
 

@@ -501,10 +501,7 @@ int dispatch_dtype(PromptArgs& args, int num_work, int head_size, int dtype, hip
 // for twice as many rows, which is worth it once the grid still fills the chip
 // several times over; smaller batches keep 128 rows for the finer grain.
 int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
-  static const int forced = [] {
-    const char* e = getenv("PA_PROMPT_WAVES");  // tuning aid: 4 or 8
-    return e ? atoi(e) : 0;
-  }();
+  static const int forced = tuning_int("PA_PROMPT_WAVES", 0);  // tuning builds: 4 or 8
   if (forced == 4 || forced == 8) return forced;
   int64_t big_blocks = 0;
   for (int s = 0; s < num_seqs; ++s) big_blocks += (cu[s + 1] - cu[s] + 255) / 256;
