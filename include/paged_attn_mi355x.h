@@ -148,6 +148,33 @@ int pa_single_query_cached_kv_attention_planned(
     int64_t total_context_len, void* stream);
 
 /*
+ * The _ws form for callers that cannot allocate device memory: code under HIP
+ * graph capture, serving loops and harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  The scratch (partition results, item list,
+ * row table) is a fixed array of PA_DECODE_STATIC_SCRATCH_BYTES inside the
+ * library's code object, one copy per GPU, held from library load until the
+ * process ends; the call allocates and frees nothing.  A launch whose
+ * pa_decode_workspace_bytes(...) exceeds that size returns
+ * PA_ERR_INVALID_ARGUMENT and launches nothing (256 sequences x 32 heads x
+ * head size 128 with contexts up to 4096 tokens need 17 MiB; use the _ws form
+ * beyond).  Results are those of the _ws form on the same arguments.  All
+ * calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (different streams, or graphs replayed concurrently) race on it; calls on
+ * one stream are ordered and safe.  Nothing in the array has to survive from
+ * one call to the next or start out as zero: every call rewrites what it
+ * reads.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress); make that call outside graph capture.
+ */
+#define PA_DECODE_STATIC_SCRATCH_BYTES ((size_t)32 << 20)
+
+int pa_single_query_cached_kv_attention_static(
+    void* out, const void* query, const void* key_cache, const void* value_cache,
+    float scale, const int32_t* block_tables, const int32_t* context_lens,
+    int num_seqs, int num_heads, int head_size, int block_size,
+    int max_num_blocks_per_seq, int max_context_len, int64_t q_stride,
+    int dtype, void* stream);
+
+/*
  * Scatter new key/value vectors into the paged caches.
  * Replaces reshape_and_cache (csrc/cache_kernels.cu:186-224; kernel :143-182).
  *

@@ -30,6 +30,7 @@ EXPORTS = (
     "pa_single_query_cached_kv_attention",
     "pa_single_query_cached_kv_attention_ws",
     "pa_single_query_cached_kv_attention_planned",
+    "pa_single_query_cached_kv_attention_static",
     "pa_decode_workspace_bytes",
     "pa_multi_query_kv_attention",
     "pa_reshape_and_cache",
@@ -65,6 +66,8 @@ def _load() -> ctypes.CDLL:
     lib.pa_single_query_cached_kv_attention.argtypes = [
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp]
     lib.pa_single_query_cached_kv_attention.restype = i32
+    lib.pa_single_query_cached_kv_attention_static.argtypes = lib.pa_single_query_cached_kv_attention.argtypes
+    lib.pa_single_query_cached_kv_attention_static.restype = i32
     lib.pa_single_query_cached_kv_attention_ws.argtypes = [
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, vp]
     lib.pa_single_query_cached_kv_attention_ws.restype = i32
@@ -132,6 +135,20 @@ def single_query_cached_kv_attention(out, query, key_cache, value_cache, scale, 
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D if head_size is None else head_size,
         block_size, block_tables.shape[1], max_context_len, query.stride(0) if S > 0 else 0,
         dtype_code(query.dtype) if dtype is None else dtype, _stream_handle(stream))
+    check(rc)
+
+
+DECODE_STATIC_SCRATCH_BYTES = 32 << 20  # PA_DECODE_STATIC_SCRATCH_BYTES
+
+
+def single_query_cached_kv_attention_static(out, query, key_cache, value_cache, scale, block_tables,
+                                            context_lens, block_size, max_context_len, stream=None) -> None:
+    """The _ws form on the library's own per-GPU scratch array: allocates nothing."""
+    S, H, D = query.shape
+    rc = lib.pa_single_query_cached_kv_attention_static(
+        out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), float(scale),
+        block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
+        max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), _stream_handle(stream))
     check(rc)
 
 

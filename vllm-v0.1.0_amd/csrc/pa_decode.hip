@@ -29,6 +29,7 @@
 #include <float.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include <algorithm>
@@ -916,10 +917,7 @@ constexpr int kListSplitPct = 50;  // kModeList: partitions when the longest row
 #endif
 
 static int split_pct() {
-  static const int pct = [] {
-    const char* e = getenv("PA_DECODE_SPLIT_PCT");  // tuning aid only: 0 = always split
-    return e ? atoi(e) : kListSplitPct;
-  }();
+  static const int pct = tuning_int("PA_DECODE_SPLIT_PCT", kListSplitPct);  // tuning builds: 0 = always split
   return pct;
 }
 
@@ -1019,10 +1017,7 @@ static int group_for(int num_heads) { return 128 / num_heads < 1 ? 1 : (128 / nu
 // (beyond that the XCDs' shares even out by themselves, and the plan kernel's
 // counting would take longer than it saves).
 static void plan_balance(PartitionPlan& p, int num_seqs, int num_heads) {
-  static const int balance = [] {
-    const char* e = getenv("PA_DECODE_BALANCE");  // tuning aid only: 0 = positional order, n = units of n sequences
-    return e ? atoi(e) : kBalanceUnit;
-  }();
+  static const int balance = tuning_int("PA_DECODE_BALANCE", kBalanceUnit);  // tuning builds: 0 = positional order, n = units of n sequences
   if (balance <= 0 || num_seqs > kMaxBalancedSeqs) return;
   int group = group_for(num_heads);
   const int unit = balance < group ? balance : group;
@@ -1054,17 +1049,11 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   int min_blocks = num_waves;
   while (min_blocks * block_size < 64) min_blocks *= 2;
   PartitionPlan p = {1, max_blocks > 0 ? max_blocks : 1, false};
-  static const int forced = [] {
-    const char* e = getenv("PA_DECODE_FORCE_PARTS");  // tuning aid only
-    return e ? atoi(e) : 0;
-  }();
+  static const int forced = tuning_int("PA_DECODE_FORCE_PARTS", 0);  // tuning builds only
   const int64_t target_wgs = 1024;
   const bool worth_it = rows <= 64 || (rows <= 256 && (int64_t)max_context_len * rows >= 256 * 1024);
   int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
-  static const int list_mode = [] {
-    const char* e = getenv("PA_DECODE_LIST");  // tuning aid only: 0 = never use the item list
-    return e ? atoi(e) : -1;
-  }();
+  static const int list_mode = tuning_int("PA_DECODE_LIST", -1);  // tuning builds: 0 = never use the item list
   int list_bpp = std::max(kListPartTokens / block_size, (max_blocks + kListMaxParts - 1) / kListMaxParts);
   list_bpp = (list_bpp + num_waves - 1) / num_waves * num_waves;
   const bool long_contexts = max_blocks > list_bpp;  // some sequence can have a second partition
@@ -1146,10 +1135,7 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.row_table = nullptr;
   a.slots_per_xcd = 0;
   a.unit = 1;
-  static const int plain_rows = [] {
-    const char* e = getenv("PA_DECODE_PLAIN_ROWS");  // tuning aid only
-    return e ? atoi(e) : kPlainOrderRows;
-  }();
+  static const int plain_rows = tuning_int("PA_DECODE_PLAIN_ROWS", kPlainOrderRows);  // tuning builds only
   a.plain_order = rows <= plain_rows ? 1 : 0;
   a.plan_tag = 0;
   if (workspace != nullptr) {
@@ -1214,7 +1200,64 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   }
 }
 
+// ---- the library's own scratch, for callers that cannot allocate ---------------
+//
+// pa_single_query_cached_kv_attention_static runs the _ws form on a scratch
+// buffer that lives in the library's code object: every GPU the library is
+// loaded on holds its own kStaticScratchBytes copy of `scratch` until the
+// process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress; the kernels are given the device address that call
+// returns for the current device, kept per device in static_scratch_ptr.
+constexpr size_t kStaticScratchBytes = PA_DECODE_STATIC_SCRATCH_BYTES;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static std::atomic<void*> static_scratch_ptr[kMaxDevices];
+
+// Device address of the current device's copy of `scratch` (looked up once per device).
+static int static_scratch(void** ptr) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(PA_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices) return fail(PA_ERR_UNSUPPORTED, "device index %d beyond the %d this library keeps scratch for", dev, kMaxDevices);
+  void* p = static_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p == nullptr) {
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr)
+      return fail(PA_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+    static_scratch_ptr[dev].store(p, std::memory_order_release);  // racing threads store the same address
+  }
+  *ptr = p;
+  return PA_OK;
+}
+
 }  // namespace pa
+
+extern "C" int pa_single_query_cached_kv_attention_static(
+    void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
+    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int dtype, void* stream) {
+  pa::clear_error();
+  size_t need = 0;
+  if (num_seqs > 0 && num_heads > 0 && max_context_len > 0 && (head_size == 64 || head_size == 80 || head_size == 96 || head_size == 128) &&
+      (block_size == 8 || block_size == 16 || block_size == 32)) {
+    const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
+    need = pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p, head_size, num_seqs);
+  }
+  if (need > pa::kStaticScratchBytes)
+    return pa::fail(PA_ERR_INVALID_ARGUMENT,
+                    "this launch needs %zu bytes of scratch, the library's static scratch holds %zu "
+                    "(num_seqs %d x num_heads %d, head size %d, max_context_len %d): use "
+                    "pa_single_query_cached_kv_attention_ws with a caller workspace",
+                    need, pa::kStaticScratchBytes, num_seqs, num_heads, head_size, max_context_len);
+  void* ws = nullptr;
+  if (need > 0) {
+    const int rc = pa::static_scratch(&ws);
+    if (rc != PA_OK) return rc;
+  }
+  return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
+                          head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, ws,
+                          ws != nullptr ? pa::kStaticScratchBytes : 0, pa::kPlanPerCall, -1, stream);
+}
 
 extern "C" int pa_single_query_cached_kv_attention(
     void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
