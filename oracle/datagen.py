@@ -441,3 +441,77 @@ def prompt_cases() -> List[PromptCase]:
                                 pad_tokens=5, seed=seed))
         seed += 1
     return cases
+
+
+# ---- scheduler output for the input builder --------------------------------------
+
+class SeqData:
+    """The three accessors of vllm.sequence.SequenceData that
+    Worker._prepare_inputs uses (vllm/worker/worker.py:151,189,192)."""
+
+    def __init__(self, tokens):
+        self.tokens = list(tokens)
+
+    def get_len(self):
+        return len(self.tokens)
+
+    def get_token_ids(self):
+        return self.tokens
+
+    def get_last_token_id(self):
+        return self.tokens[-1]
+
+
+def make_input_batch(seed: int, num_prompt_groups: int, num_gen_groups: int, block_size: int,
+                     profiling: bool = False) -> list:
+    """A scheduler output in the shape of List[SequenceGroupMetadata]
+    (vllm/sequence.py): prompt groups of one or two sequences sharing a prompt
+    and its block table, generation groups of one to three sequences with
+    their own tables, prompt and generation groups interleaved.  profiling:
+    prompt groups carry block_tables=None, as in the memory-profiling run
+    (vllm/worker/worker.py:160-164)."""
+    from types import SimpleNamespace
+    groups = []
+    next_id, next_block = 0, 1
+    r = randint(4 * (num_prompt_groups + num_gen_groups) + 8, seed, 1, 70)
+    k = 0
+    for _ in range(num_prompt_groups):
+        n = int(r[k]); k += 1
+        ids = [next_id, next_id + 1] if r[k] % 3 == 0 else [next_id]
+        k += 1
+        next_id += len(ids)
+        toks = [int(t) for t in randint(n, seed + next_id, 0, 31999)]
+        nb = (n + block_size - 1) // block_size
+        table = list(range(next_block, next_block + nb))[::-1]
+        next_block += nb
+        groups.append(SimpleNamespace(
+            request_id=str(next_id), is_prompt=True, seq_data={i: SeqData(toks) for i in ids},
+            sampling_params=SimpleNamespace(n=len(ids)),
+            block_tables=None if profiling else {i: table for i in ids}))
+    for _ in range(num_gen_groups):
+        nseq = 1 + int(r[k]) % 3; k += 1
+        seq_data, tables = {}, {}
+        for _s in range(nseq):
+            n = int(r[k % len(r)]) + _s; k += 1
+            toks = [int(t) for t in randint(n, seed + 100 + next_id, 0, 31999)]
+            nb = (n + block_size - 1) // block_size
+            tables[next_id] = list(range(next_block, next_block + nb))
+            next_block += nb
+            seq_data[next_id] = SeqData(toks)
+            next_id += 1
+        groups.append(SimpleNamespace(request_id=str(next_id), is_prompt=False, seq_data=seq_data,
+                                      sampling_params=SimpleNamespace(n=nseq), block_tables=tables))
+    # the scheduler may interleave prompt and generation groups
+    order = permutation(len(groups), seed + 7)
+    return [groups[i] for i in order]
+
+
+def input_batch_cases() -> List[dict]:
+    """(seed, prompt groups, generation groups, block size, profiling) of the input-builder fixtures."""
+    cases = []
+    for block_size in (8, 16, 32):
+        for shape in ((3, 5), (0, 7), (4, 0), (1, 1), (0, 0), (9, 40)):
+            cases.append({"seed": 11 + block_size, "prompts": shape[0], "gens": shape[1],
+                          "block_size": block_size, "profiling": False})
+    cases.append({"seed": 5, "prompts": 3, "gens": 0, "block_size": 16, "profiling": True})
+    return cases

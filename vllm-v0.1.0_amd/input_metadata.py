@@ -3,8 +3,10 @@
 Mirror of vllm/model_executor/input_metadata.py:10-54 (same constructor
 arguments, same derived attributes).  The one difference: `attn_bias` is a
 plain description of the block-diagonal causal mask (the prompt lengths and
-their prefix sums) instead of an xformers object, because prompt attention is
-outside this path and runs on torch SDPA here.
+their prefix sums) instead of an xformers object: it only carries the
+sequence lengths that attention_ops.multi_query_kv_attention (the MFMA prompt
+kernel of this package, csrc/pa_prefill.hip) takes, both from
+layers/attention.py and through the xformers import shim under compat/.
 """
 from __future__ import annotations
 
