@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the PagedAttention decode hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--tp]
 
 Metric (BASELINE.json): output tokens/s + paged-attention HBM GB/s, LLaMA-7B
 TP=1, batch 256.  One STEP is one decode iteration of the hot path over the
@@ -12,22 +12,38 @@ the batch's new K/V vectors into that layer's paged cache and
 distinct physical block; one 2 GiB K and one 2 GiB V cache per layer, all
 resident in HBM before timing starts).  The attention's launch plan (the order
 in which rows are dealt to the XCDs) depends on the context lengths only and is
-made once per step, by layer 0, as in this package's PagedAttention layer.  value = tokens produced per second by that path =
-batch * steps / elapsed.  The GEMMs, sampler and scheduler of the full model
-are outside this path and are not run.
+made once per step, by layer 0, as in this package's PagedAttention layer.
+value = tokens produced per second by that path = batch * steps / elapsed.  The
+GEMMs, sampler and scheduler of the full model are outside this path.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-runs the same per-GPU workload on its own caches: the (sequence, head) units
-are independent, so there is no data-path collective; value aggregates all
-ranks (weak scaling).  Timing is barrier + synchronize on both sides, MAX over
-ranks.
+N > 1 (launched by torch.distributed.run, one rank per GPU), two forms:
+
+  default   every rank runs the whole per-GPU workload on its own caches: the
+            (sequence, head) units are independent, no data-path collective;
+            value aggregates all ranks ("scaling": "weak").  The line also
+            carries a "tp" object: the head-sharded form below measured in the
+            same process.
+  --tp      the reference's tensor parallelism: rank r owns heads
+            [r*H/N, (r+1)*H/N) and their K/V; per layer reshape_and_cache +
+            attention on the local heads, the row-parallel o_proj matmul into
+            the all-reduce launcher's buffer, and the RCCL all-reduce of
+            [batch, hidden] on a side HIP stream, overlapped with the next
+            layer's cache write and attention.  Total work is fixed
+            ("scaling": "strong"); value = batch * steps / elapsed.
+
+Timing is barrier + synchronize on both sides, MAX over ranks.
 
 The JSON line also carries
-  roofline      achieved HBM GB/s of the decode kernel: algorithmic bytes per
-                launch / mean launch time measured with HIP events on the
-                launch stream, against the 8 TB/s HBM3E peak;
-  cpu_baseline  the C oracle (a CPU port of the reference algorithm) timed on
-                this host for one layer of the same workload, rank 0, N=1 only.
+  roofline      decode kernel: algorithmic bytes per launch / MEDIAN launch
+                time measured with HIP events on the launch stream, against the
+                8 TB/s HBM3E peak; the same for the operator with the
+                reference's signature; `traffic` = PMC bytes of a committed
+                rocprofv3 pass over this command (`traffic_source` names it);
+  c2            the same measurement on the microbenchmark shape of
+                BASELINE.json configs[1] (12 heads x 64);
+  cpu_baseline  CPU statements of the path timed on this host, rank 0, N=1: the
+                C oracle on one layer of the workload, and two torch-CPU
+                statements (per-token loop, vectorised gather) on a slice.
 """
 from __future__ import annotations
 
@@ -45,8 +61,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
 
 WORKLOADS = {
     # name: (num_heads, head_size, num_layers, description)
-    "llama7b": (32, 128, 32, "LLaMA-7B decode hot path"),
-    "opt125m_c2": (12, 64, 12, "microbench shape of BASELINE.json configs[1] (12 heads x 64)"),
+    "llama7b": (32, 128, 32, "LLaMA-7B"),
+    "llama13b": (40, 128, 40, "LLaMA-13B"),
+    "neox20b": (64, 96, 44, "GPT-NeoX-20B"),
+    "opt125m_c2": (12, 64, 12, "OPT-125m (microbench shape of BASELINE.json configs[1])"),
 }
 
 
@@ -61,23 +79,26 @@ def algorithmic_bytes(ctx_lens, num_heads, head_size, block_size, elem_size):
     return kv + qo + tbl
 
 
+PMC_TRAFFIC_FILE = os.path.join("profiles", "pmc_hbm_traffic_latest.json")
+
+
 def pmc_traffic(kernel_substr, args):
-    """HBM bytes per launch of the named kernel from the committed PMC passes
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command; counters
-    cannot be read from inside the process).  Only valid for the default
-    workload the passes were taken on; otherwise None."""
+    """(HBM bytes per launch of the named kernel, where that figure comes from).
+    Hardware counters cannot be read from inside the process: the figure is from
+    the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) over this same
+    command, valid only for the default workload; otherwise (None, None)."""
     if (args.workload, args.batch, args.ctx, args.block_size, args.dtype) != ("llama7b", 256, 1024, 16, "float16"):
-        return None
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+        return None, None
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, PMC_TRAFFIC_FILE)) as f:
             table = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, None
     for name, row in table.items():
         if kernel_substr in name:
-            return row.get("hbm_traffic_bytes_per_launch")
-    return None
+            return row.get("hbm_traffic_bytes_per_launch"), \
+                f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass over this command, not this run)"
+    return None, None
 
 
 def parse_args(argv=None):
@@ -85,6 +106,12 @@ def parse_args(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--tp", action="store_true",
+                   help="N > 1: shard heads over the ranks (tensor parallel) with the o_proj all-reduce in the step")
+    p.add_argument("--tp-emulate", type=int, default=0, metavar="N",
+                   help="one GPU: run rank 0's share of a tensor-parallel group of N (heads/N, o_proj shard) with the "
+                        "collective replaced by a local add of a same-sized 'remote' partial sum: the shard's device "
+                        "time without xGMI; the line says so")
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="llama7b")
     p.add_argument("--batch", type=int, default=256)
     p.add_argument("--ctx", type=int, default=1024)
@@ -92,9 +119,14 @@ def parse_args(argv=None):
     p.add_argument("--layers", type=int, default=0, help="override the number of layers (0 = model's)")
     p.add_argument("--dtype", choices=["float16", "bfloat16", "float32"], default="float16")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
-                   help="CPU work the cpu_baseline sample is sized to (one layer of the workload, repeated)")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
+                   help="CPU work the C-oracle sample is sized to (one layer of the workload, repeated)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-c2", action="store_true", help="skip the secondary microbench-shape measurement")
+    p.add_argument("--no-tp-leg", action="store_true", help="N > 1 without --tp: skip the extra head-sharded measurement")
+    p.add_argument("--roofline-only", action="store_true",
+                   help="launch nothing but isolated decode kernels (5 warm-ups + 40 timed): the command to put "
+                        "under rocprofv3 --kernel-trace so that its per-dispatch median reproduces roofline.frac")
     p.add_argument("--cpu-plumbing-test", action="store_true",
                    help="run only the multi-process plumbing on CPU (gloo) with a no-op step; used by tests")
     return p.parse_args(argv)
@@ -157,20 +189,26 @@ def timed_region(dist: Dist, device, step_fn, steps: int, warmup: int, sync_fn):
     return dist.max_float(elapsed, device)
 
 
-def result_line(args, n_gpus, elapsed, units_all_ranks, unit_name, config, extra):
+def metric_text(args, model_name, tp):
+    form = f"TP={tp}" if tp > 1 else "TP=1"
+    per = "" if tp > 1 else " per GPU"
+    return ("output tokens/s through the PagedAttention decode hot path "
+            "(reshape_and_cache + single_query_cached_kv_attention, all layers), "
+            f"{model_name} {form}, batch {args.batch}{per}")
+
+
+def result_line(args, n_gpus, elapsed, units, unit_name, config, extra, metric, scaling="weak"):
     ms = elapsed * 1e3 / args.steps
     out = {
-        "metric": "output tokens/s through the PagedAttention decode hot path "
-                  "(reshape_and_cache + single_query_cached_kv_attention, all layers), "
-                  "LLaMA-7B TP=1, batch 256 per GPU",
-        "value": units_all_ranks / elapsed,
+        "metric": metric,
+        "value": units / elapsed,
         "unit": unit_name,
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": {"float16": "f16", "bfloat16": "bf16", "float32": "f32"}[args.dtype],
         "data": "synthetic",
@@ -188,12 +226,281 @@ def cpu_plumbing_main(args):
     device = torch.device("cpu")
     cost = 0.002 * (1 + dist.rank)  # the slowest rank must set the time
     elapsed = timed_region(dist, device, lambda: time.sleep(cost), args.steps, args.warmup, lambda: None)
-    units = dist.sum_float(float(args.batch * args.steps), device)
+    if args.tp:  # strong scaling: every rank works on the same tokens
+        units, scaling = float(args.batch * args.steps), "strong"
+    else:
+        units, scaling = dist.sum_float(float(args.batch * args.steps), device), "weak"
     if dist.rank == 0:
         line = result_line(args, dist.world, elapsed, units, "tokens/s",
-                           {"workload": "cpu plumbing test (no-op step)"}, {})
+                           {"workload": "cpu plumbing test (no-op step)"}, {},
+                           metric_text(args, "no model", dist.world if args.tp else 1), scaling)
         print(json.dumps(line))
     dist.close()
+
+
+# ---- measurement helpers -----------------------------------------------------------
+
+def time_launches(torch, fn, n, warmup=3):
+    """Sorted per-launch milliseconds of n calls of fn(i), HIP events on the current stream."""
+    for i in range(warmup):
+        fn(i)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize()
+    for i, (e0, e1) in enumerate(evs):
+        e0.record()
+        fn(i)
+        e1.record()
+    torch.cuda.synchronize()
+    return sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+
+
+def median(xs):
+    return xs[len(xs) // 2]
+
+
+class Workload:
+    """Synthetic decode-step inputs of one (sharded) model, resident in HBM."""
+
+    def __init__(self, torch, device, H, D, L, S, CTX, B, tdtype, free_fraction=0.85, rank=0, note=None):
+        es = torch.tensor([], dtype=tdtype).element_size()
+        x = 16 // es
+        self.H, self.D, self.S, self.CTX, self.B, self.es = H, D, S, CTX, B, es
+        blocks_per_seq = (CTX + B - 1) // B
+        NB = S * blocks_per_seq
+        self.cache_bytes = 2 * NB * H * D * B * es
+        free_b, _ = torch.cuda.mem_get_info(device)
+        if L * self.cache_bytes > free_fraction * free_b:
+            L_fit = max(1, int(free_fraction * free_b // self.cache_bytes))
+            if rank == 0:
+                print(f"# {L} layers of KV cache ({L * self.cache_bytes / 2**30:.0f} GiB) do not fit; using {L_fit}",
+                      file=sys.stderr)
+            L = L_fit
+        self.L = L
+        self.key_caches, self.value_caches = [], []
+        for _ in range(L):
+            kc = torch.empty(NB, H, D // x, B, x, dtype=tdtype, device=device)
+            vc = torch.empty(NB, H, D, B, dtype=tdtype, device=device)
+            kc.normal_(0.0, 0.5)
+            vc.normal_(0.0, 0.5)
+            self.key_caches.append(kc)
+            self.value_caches.append(vc)
+        self.qkv = torch.empty(S, 3, H, D, dtype=tdtype, device=device).normal_(0.0, 0.5)
+        self.query, self.key, self.value = self.qkv.unbind(dim=1)  # strided slices of the fused projection
+        self.out = torch.empty(S, H, D, dtype=tdtype, device=device)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(0)  # the same tables on every rank, as the engine hands every worker the same scheduler output
+        self.block_tables = torch.randperm(NB, generator=g).to(torch.int32).reshape(S, blocks_per_seq).to(device)
+        self.ctx_list = [CTX] * S
+        self.context_lens = torch.tensor(self.ctx_list, dtype=torch.int32, device=device)
+        pos = CTX - 1  # the new token is the last of the context
+        self.slot_mapping = (self.block_tables[:, pos // B].to(torch.int64) * B + pos % B).to(torch.int32)
+        self.scale = 1.0 / D ** 0.5
+        self.total_ctx = S * CTX
+
+    def bytes_per_launch(self):
+        return algorithmic_bytes(self.ctx_list, self.H, self.D, self.B, self.es)
+
+
+def decode_roofline(torch, attention_ops, cache_ops, w, workspace, n_launch):
+    """Isolated launches of the decode operator on workload w, timed one by one."""
+    def planned(i):
+        l = i % w.L
+        attention_ops.single_query_cached_kv_attention_planned(
+            w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, w.B, w.CTX,
+            workspace, True, w.total_ctx)
+
+    def reference_signature(i):
+        l = i % w.L
+        attention_ops.single_query_cached_kv_attention(
+            w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, w.B, w.CTX)
+
+    # make the plan the timed launches reuse
+    attention_ops.single_query_cached_kv_attention_planned(
+        w.out, w.query, w.key_caches[0], w.value_caches[0], w.scale, w.block_tables, w.context_lens, w.B, w.CTX,
+        workspace, False, w.total_ctx)
+    times = time_launches(torch, planned, n_launch)
+    ref_times = time_launches(torch, reference_signature, n_launch)
+    nbytes = w.bytes_per_launch()
+    med = median(times)
+    achieved = nbytes / (med * 1e-3) / 1e9
+    return {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "bytes_per_launch": nbytes,
+        "launch_ms_median": med,
+        "launch_ms_mean": sum(times) / len(times),
+        "launch_ms_min": times[0],
+        "launch_ms_max": times[-1],
+        "launches_timed": n_launch,
+        "timing": "HIP events around each launch on the launch stream; achieved / frac use the median",
+        "reference_signature_launch_ms": median(ref_times),
+        "reference_signature_achieved": nbytes / (median(ref_times) * 1e-3) / 1e9,
+        "reference_signature_note": "attention_ops.single_query_cached_kv_attention(out, query, key_cache, value_cache, "
+                                    "scale, block_tables, context_lens, block_size, max_context_len): what the unchanged "
+                                    "reference caller invokes; plans per call, scratch from torch's allocator",
+    }
+
+
+def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=None, emulate=0):
+    """The head-sharded step: per layer reshape_and_cache + attention on this rank's heads, the
+    row-parallel o_proj matmul into the launcher's ring buffer, the all-reduce on the side stream.
+    Returns (elapsed seconds MAX over ranks, info dict)."""
+    from vllm_amd.worker import GraphAllReduce, TensorParallelDecodeStep, head_shard
+    tp, rank = (emulate, 0) if emulate else (dist.world, dist.rank)
+    lo, hi = head_shard(rank, tp, H)
+    Hl = hi - lo
+    hidden = H * D
+    S, CTX, B = args.batch, args.ctx, args.block_size
+    if shared_caches is None:
+        w = Workload(torch, device, Hl, D, L, S, CTX, B, tdtype, rank=rank)
+    else:
+        # carve the local-heads caches out of the replica leg's allocations: no second set of caches
+        w = shared_caches
+        x = 16 // w.es
+        NB = w.key_caches[0].shape[0]
+        n = NB * Hl * D * B
+        kcs = [kc.view(-1)[:n].view(NB, Hl, D // x, B, x) for kc in w.key_caches]
+        vcs = [vc.view(-1)[:n].view(NB, Hl, D, B) for vc in w.value_caches]
+        local = Workload.__new__(Workload)
+        local.__dict__.update(w.__dict__)
+        local.H, local.key_caches, local.value_caches = Hl, kcs, vcs
+        local.qkv = w.qkv[:, :, :Hl].contiguous()  # the local fused projection holds the local heads only
+        local.query, local.key, local.value = local.qkv.unbind(dim=1)
+        local.out = torch.empty(S, Hl, D, dtype=tdtype, device=device)
+        w = local
+    L = w.L
+    w_o = [torch.empty(Hl * D, hidden, dtype=tdtype, device=device).normal_(0.0, hidden ** -0.5) for _ in range(L)]
+    reduce_fn = None
+    if emulate:
+        remote = torch.zeros(S, hidden, dtype=tdtype, device=device)
+        reduce_fn = lambda t: t.add_(remote[:t.shape[0]])  # noqa: E731  (stand-in: same bytes, no xGMI)
+    launcher = GraphAllReduce(S, hidden, tdtype, device=device, reduce_fn=reduce_fn)
+    launcher.precapture([S])  # no capture inside the timed loop
+    step_obj = TensorParallelDecodeStep(rank, tp, H, D, w.scale, launcher, pkg.attention_ops, pkg.cache_ops)
+    dense_out = torch.empty(S, hidden, dtype=tdtype, device=device) if tp == 1 else None
+
+    def step():
+        step_obj.begin_step()
+        pend = []
+        for l in range(L):
+            p = step_obj.layer(w.query, w.key, w.value, w.key_caches[l], w.value_caches[l], w.slot_mapping,
+                               w.block_tables, w.context_lens, CTX, w_o[l], w.out, w.total_ctx)
+            if p is None:  # one rank: the same matmul, nothing to sum
+                torch.matmul(w.out.view(S, Hl * D), w_o[l], out=dense_out)
+            else:
+                pend.append(p)
+        for p in pend[-2:]:  # earlier ones were fenced when their ring buffer came round again
+            p.wait()
+
+    elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
+    info = {
+        "tp": tp, "heads_per_rank": Hl, "layers": L, "scaling": "strong",
+        "value": S * args.steps / elapsed, "unit": "tokens/s", "ms_per_step": elapsed * 1e3 / args.steps,
+        "step": "per layer: reshape_and_cache + single_query_cached_kv_attention on the local heads, row-parallel "
+                "o_proj matmul [batch, heads/tp * head_size] x [.., hidden] into the all-reduce buffer, RCCL "
+                "all-reduce of [batch, hidden] on a side HIP stream (event hand-off, HIP graph replay), "
+                "overlapped with the next layer's cache write and attention",
+        "all_reduce_bytes": S * hidden * w.es, "all_reduces_per_step": L if tp > 1 else 0,
+    }
+    if emulate:
+        info["emulated"] = ("one GPU ran rank 0's share; the all-reduce is replaced by a local add of a same-sized "
+                            "buffer on the side stream: device time of the shard, no xGMI traffic")
+    if tp > 1:
+        # the collective alone: launch + wait, back to back
+        def one(i):
+            launcher.launch_async(launcher.next_buffer(S)).wait()
+        ts = time_launches(torch, one, 40, warmup=5)
+        info["all_reduce_isolated_us_median"] = median(ts) * 1e3
+        if not emulate:
+            info["all_reduce_isolated_us_max_over_ranks"] = dist.max_float(median(ts) * 1e3, device)
+    return elapsed, info, w
+
+
+def cpu_baseline(torch, np, args, w, L, attention_ops):
+    """CPU statements of the path on this host: C oracle on one layer; two torch statements on a slice."""
+    from oracle import pa_oracle, torch_cpu_baseline
+    host_cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = host_cores
+    # the box gives a one-GPU job a share of the host: OMP_NUM_THREADS is that share where it is set
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    threads = max(1, min(usable, share) if share > 0 else usable)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
+    dname = args.dtype
+    S, H, CTX = w.S, w.H, w.CTX
+
+    def to_np(t):
+        t = t.cpu().contiguous()
+        return t.view(torch.int16).numpy().view(np.uint16) if dname == "bfloat16" else t.numpy()
+
+    kc_t, vc_t = w.key_caches[0].cpu(), w.value_caches[0].cpu()
+    kc_np, vc_np = to_np(kc_t), to_np(vc_t)
+    qkv_np = to_np(w.qkv)
+    q_np, k_np, v_np = qkv_np[:, 0], qkv_np[:, 1], qkv_np[:, 2]
+    bt_np, cl_np = w.block_tables.cpu().numpy(), w.context_lens.cpu().numpy()
+    sm_np = w.slot_mapping.cpu().numpy()
+    pa_oracle.lib()
+
+    # One layer's caches (4 GiB per pass: nothing stays in the CPU caches), walked until about
+    # cpu_baseline_seconds of CPU work are on the clock: one untimed pass sizes the sample.
+    def one_layer():
+        pa_oracle.reshape_and_cache(k_np, v_np, kc_np, vc_np, sm_np, dname)
+        return pa_oracle.single_query_cached_kv_attention(q_np, kc_np, vc_np, w.scale, bt_np, cl_np, dname)
+    t0 = time.perf_counter()
+    ref = one_layer()
+    t_first = time.perf_counter() - t0
+    reps = max(3, min(64, int(args.cpu_baseline_seconds / max(t_first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ref = one_layer()
+    t_layer = (time.perf_counter() - t0) / reps
+    nbytes = w.bytes_per_launch()
+    res = {
+        "value": S / (t_layer * L),
+        "unit": "tokens/s",
+        "cores": threads,
+        "host_cores": host_cores,
+        "cores_note": f"{threads} threads = this job's share of the host (OMP_NUM_THREADS / affinity); "
+                      f"os.cpu_count() of the machine = {host_cores}",
+        "kind": "port",
+        "sample": f"C oracle (OpenMP, {threads} threads) on one layer of the same workload "
+                  f"({S} seqs x {H} heads x ctx {CTX}), {reps} passes, {t_layer:.2f} s per layer; "
+                  f"a step is {L} layers",
+        "layer_seconds": t_layer,
+        "gbps": nbytes / t_layer / 1e9,
+    }
+    # the GPU result of layer 0 doubles as an end-of-bench parity check
+    attention_ops.single_query_cached_kv_attention(
+        w.out, w.query, w.key_caches[0], w.value_caches[0], w.scale, w.block_tables, w.context_lens, w.B, CTX)
+    torch.cuda.synchronize()
+    got = w.out.float().cpu().numpy()
+    want = (torch.from_numpy(ref.view(np.int16)).view(torch.bfloat16).float().numpy()
+            if dname == "bfloat16" else ref.astype(np.float32))
+    res["max_abs_err_gpu_vs_cpu"] = float(np.abs(got - want).max())
+
+    # torch on the CPU, fp32 accumulation, the decode attention of a slice of the same layer
+    # (the cache write is not part of these statements)
+    q_t = w.qkv.cpu()[:, 0]
+    bt_t, cl_t = w.block_tables.cpu(), w.context_lens.cpu()
+    for name, fn, n_seqs in (("torch_loop", torch_cpu_baseline.decode_loop, 4),
+                             ("torch_vectorised", torch_cpu_baseline.decode_vectorised, 32)):
+        n_seqs = min(n_seqs, S)
+        t0 = time.perf_counter()
+        o = fn(q_t[:n_seqs], kc_t, vc_t, bt_t[:n_seqs], cl_t[:n_seqs], w.scale)
+        dt = time.perf_counter() - t0
+        b = algorithmic_bytes(w.ctx_list[:n_seqs], H, w.D, w.B, w.es)
+        res[name] = {
+            "sample": f"decode attention of {n_seqs} of the {S} sequences of one layer, {threads} torch threads, fp32 accumulation",
+            "seconds": dt, "gbps": b / dt / 1e9, "tokens_per_s_whole_model": n_seqs / (dt * L),
+            "max_abs_err_vs_c_oracle": float(np.abs(o.numpy() - want[:n_seqs]).max()),
+        }
+    return res
 
 
 def main(argv=None):
@@ -205,12 +512,10 @@ def main(argv=None):
     import torch
     import __graft_entry__
 
-    H, D, L_model, desc = WORKLOADS[args.workload]
+    H, D, L_model, model_name = WORKLOADS[args.workload]
     L = args.layers or L_model
     S, CTX, B = args.batch, args.ctx, args.block_size
     tdtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[args.dtype]
-    es = torch.tensor([], dtype=tdtype).element_size()
-    x = 16 // es
 
     dist = Dist("nccl")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -218,162 +523,109 @@ def main(argv=None):
     device = torch.device("cuda", dist.local_rank)
     pkg = __graft_entry__.load_package()
     attention_ops, cache_ops = pkg.attention_ops, pkg.cache_ops
-
-    # ---- synthetic inputs, resident in HBM before timing ----------------------
     torch.manual_seed(0)
-    blocks_per_seq = (CTX + B - 1) // B
-    NB = S * blocks_per_seq
-    cache_bytes = 2 * NB * H * D * B * es
-    free_b, _ = torch.cuda.mem_get_info(device)
-    if L * cache_bytes > 0.85 * free_b:
-        L_fit = max(1, int(0.85 * free_b // cache_bytes))
-        if dist.rank == 0:
-            print(f"# {L} layers of KV cache ({L * cache_bytes / 2**30:.0f} GiB) do not fit; using {L_fit}",
-                  file=sys.stderr)
-        L = L_fit
-    key_caches, value_caches = [], []
-    for _ in range(L):
-        kc = torch.empty(NB, H, D // x, B, x, dtype=tdtype, device=device)
-        vc = torch.empty(NB, H, D, B, dtype=tdtype, device=device)
-        kc.normal_(0.0, 0.5)
-        vc.normal_(0.0, 0.5)
-        key_caches.append(kc)
-        value_caches.append(vc)
-    qkv = torch.empty(S, 3, H, D, dtype=tdtype, device=device).normal_(0.0, 0.5)
-    query, key, value = qkv.unbind(dim=1)  # strided slices of the fused projection
-    out = torch.empty(S, H, D, dtype=tdtype, device=device)
-    g = torch.Generator(device="cpu")
-    g.manual_seed(0)
-    block_tables = torch.randperm(NB, generator=g).to(torch.int32).reshape(S, blocks_per_seq).to(device)
-    ctx_list = [CTX] * S
-    context_lens = torch.tensor(ctx_list, dtype=torch.int32, device=device)
-    pos = CTX - 1  # the new token is the last of the context
-    slot_mapping = (block_tables[:, pos // B].to(torch.int64) * B + pos % B).to(torch.int32)
-    scale = 1.0 / D ** 0.5
 
+    if args.tp or args.tp_emulate:
+        # ---- the reference's tensor parallelism: heads sharded, o_proj all-reduce in the step ----
+        assert not (args.tp_emulate and dist.active), "--tp-emulate is a one-GPU mode"
+        elapsed, info, w = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, emulate=args.tp_emulate)
+        n_tp = info["tp"]
+        if dist.rank == 0:
+            config = {
+                "workload": f"{model_name} decode hot path, heads sharded over {n_tp} GPUs"
+                            f"{' (EMULATED on one GPU, see tp.emulated)' if args.tp_emulate else ''}: {info['layers']} layers x "
+                            f"({info['step']}), batch {S}, {info['heads_per_rank']} of {H} heads x {D} per GPU, "
+                            f"block {B}, ctx {CTX}, distinct physical blocks",
+                "batch": S, "num_heads": H, "heads_per_gpu": info["heads_per_rank"], "head_size": D, "block_size": B,
+                "context_len": CTX, "layers": info["layers"], "sharding": "heads/tp", "parallelism": f"tp{n_tp}",
+            }
+            extra = {"tp": {k: v for k, v in info.items() if k not in ("value", "unit", "ms_per_step", "step")}}
+            print(json.dumps(result_line(args, dist.world, elapsed, float(S * args.steps), "tokens/s", config, extra,
+                                         metric_text(args, model_name, n_tp), "strong")))
+        dist.close()
+        return
+
+    # ---- synthetic inputs, resident in HBM before timing ----------------------------------
+    w = Workload(torch, device, H, D, L, S, CTX, B, tdtype, rank=dist.rank)
+    L = w.L
     # The layers of a step share context_lens, hence the launch plan that depends on them
     # alone: layer 0 makes it into the step's workspace, the others reuse it (what
     # PagedAttention.forward of this package does through the step's InputMetadata).
     ws_bytes = attention_ops.decode_workspace_bytes(S, H, D, B, CTX)
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    workspace = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
+
+    if args.roofline_only:
+        roof = decode_roofline(torch, attention_ops, cache_ops, w, workspace, 40)
+        if dist.rank == 0:
+            print(json.dumps({"roofline": roof}))
+        dist.close()
+        return
 
     def step():
         for l in range(L):
-            cache_ops.reshape_and_cache(key, value, key_caches[l], value_caches[l], slot_mapping)
+            cache_ops.reshape_and_cache(w.key, w.value, w.key_caches[l], w.value_caches[l], w.slot_mapping)
             attention_ops.single_query_cached_kv_attention_planned(
-                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
-                workspace, l > 0, S * CTX)
+                w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, B, CTX,
+                workspace, l > 0, w.total_ctx)
 
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     units = dist.sum_float(float(S * args.steps), device)
 
     extra = {}
-    # ---- roofline of the dominant kernel (decode attention) --------------------
+    # ---- roofline of the dominant kernel (decode attention) ------------------------------------
     if not args.no_roofline and dist.rank == 0:
-        n_launch = max(2 * L, 20)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(n_launch)]
-        torch.cuda.synchronize()
-        for i, (e0, e1) in enumerate(evs):
-            l = i % L
-            e0.record()
-            attention_ops.single_query_cached_kv_attention_planned(
-                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
-                workspace, True, S * CTX)  # the plan of the timed steps above is still in the workspace
-            e1.record()
-        torch.cuda.synchronize()
-        times_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-        mean_ms = sum(times_ms) / len(times_ms)
-        nbytes = algorithmic_bytes(ctx_list, H, D, B, es)
-        achieved = nbytes / (mean_ms * 1e-3) / 1e9
+        roof = decode_roofline(torch, attention_ops, cache_ops, w, workspace, max(2 * L, 20))
+        roof["kernel"] = "pa_decode_kernel (single_query_cached_kv_attention)"
+        roof["traffic"], roof["traffic_source"] = pmc_traffic("pa_decode_kernel", args)
         # The same kernel inside the step, i.e. right after reshape_and_cache has written this
-        # layer's new K/V: those launches run a few percent slower (the first read of the
-        # just-written lines), and a kernel trace of this command averages over both kinds.
+        # layer's new K/V; a kernel trace of the whole command averages over both kinds.
         evs2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2 * L)]
         for i, (e0, e1) in enumerate(evs2):
             l = i % L
-            cache_ops.reshape_and_cache(key, value, key_caches[l], value_caches[l], slot_mapping)
+            cache_ops.reshape_and_cache(w.key, w.value, w.key_caches[l], w.value_caches[l], w.slot_mapping)
             e0.record()
             attention_ops.single_query_cached_kv_attention_planned(
-                out, query, key_caches[l], value_caches[l], scale, block_tables, context_lens, B, CTX,
-                workspace, True, S * CTX)
+                w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, B, CTX,
+                workspace, True, w.total_ctx)
             e1.record()
         torch.cuda.synchronize()
-        in_step_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs2) / len(evs2)
-        extra["roofline"] = {
-            "kernel": "pa_decode_kernel (single_query_cached_kv_attention)",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic("pa_decode_kernel", args),
-            "bytes_per_launch": nbytes,
-            "launch_ms_mean": mean_ms,
-            "launch_ms_median": times_ms[len(times_ms) // 2],
-            "launch_ms_min": times_ms[0],
-            "launches_timed": n_launch,
-            "in_step_launch_ms_mean": in_step_ms,
-            "in_step_achieved": nbytes / (in_step_ms * 1e-3) / 1e9,
-        }
+        in_step = sorted(e0.elapsed_time(e1) for e0, e1 in evs2)
+        roof["in_step_launch_ms_median"] = median(in_step)
+        roof["in_step_achieved"] = roof["bytes_per_launch"] / (median(in_step) * 1e-3) / 1e9
+        extra["roofline"] = roof
 
-    # ---- CPU baseline: the C oracle on this host, one layer of the workload ----
+    # ---- the microbenchmark shape of BASELINE.json configs[1], same measurement -----------------
+    if not args.no_c2 and not args.no_roofline and dist.rank == 0 and args.workload != "opt125m_c2":
+        H2, D2, _, name2 = WORKLOADS["opt125m_c2"]
+        w2 = Workload(torch, device, H2, D2, 4, 256, 1024, 16, torch.float16, free_fraction=0.5)
+        ws2 = torch.empty(max(attention_ops.decode_workspace_bytes(256, H2, D2, 16, 1024), 8), dtype=torch.uint8,
+                          device=device)
+        c2 = decode_roofline(torch, attention_ops, cache_ops, w2, ws2, 40)
+        c2["workload"] = ("single_query_cached_kv_attention microbench: bs 256, 12 heads, head_size 64, block_size 16, "
+                          "ctx 1024, fp16, distinct physical blocks, 4 layers' caches walked in turn")
+        extra["c2"] = c2
+        del w2, ws2
+
+    # ---- N > 1: the head-sharded form measured in the same process ---------------------------------
+    if dist.active and not args.no_tp_leg and H % dist.world == 0:
+        tp_elapsed, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w)
+        extra["tp"] = info
+
+    # ---- CPU baseline --------------------------------------------------------------------------------
     if not args.no_cpu_baseline and dist.rank == 0 and dist.world == 1:
-        from oracle import pa_oracle
-        threads = max(1, min(16, os.cpu_count() or 1))
-        os.environ["OMP_NUM_THREADS"] = str(threads)
-        dname = args.dtype
-        def to_np(t):
-            t = t.cpu().contiguous()
-            return t.view(torch.int16).numpy().view(np.uint16) if dname == "bfloat16" else t.numpy()
-        kc_np, vc_np = to_np(key_caches[0]), to_np(value_caches[0])
-        q_np = to_np(qkv)[:, 0]
-        k_np, v_np = to_np(qkv)[:, 1], to_np(qkv)[:, 2]
-        bt_np, cl_np = block_tables.cpu().numpy(), context_lens.cpu().numpy()
-        sm_np = slot_mapping.cpu().numpy()
-        pa_oracle.lib()
-        # One layer's caches (4 GiB per pass: nothing stays in the CPU caches), walked
-        # until about 12 s of CPU work are on the clock: one untimed pass sizes the sample.
-        def one_layer():
-            pa_oracle.reshape_and_cache(k_np, v_np, kc_np, vc_np, sm_np, dname)
-            return pa_oracle.single_query_cached_kv_attention(q_np, kc_np, vc_np, scale, bt_np, cl_np, dname)
-        t0 = time.perf_counter()
-        ref = one_layer()
-        t_first = time.perf_counter() - t0
-        reps = max(3, min(64, int(args.cpu_baseline_seconds / max(t_first, 1e-3))))
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            ref = one_layer()
-        t_layer = (time.perf_counter() - t0) / reps
-        extra["cpu_baseline"] = {
-            "value": S / (t_layer * L),
-            "unit": "tokens/s",
-            "cores": threads,
-            "kind": "port",
-            "sample": f"C oracle (OpenMP, {threads} threads) on one layer of the same workload "
-                      f"({S} seqs x {H} heads x ctx {CTX}), {reps} passes, {t_layer:.2f} s per layer; "
-                      f"a step is {L} layers",
-            "layer_seconds": t_layer,
-        }
-        # the GPU result of layer 0 doubles as an end-of-bench parity check
-        attention_ops.single_query_cached_kv_attention(
-            out, query, key_caches[0], value_caches[0], scale, block_tables, context_lens, B, CTX)
-        torch.cuda.synchronize()
-        got = out.float().cpu().numpy()
-        want = (torch.from_numpy(ref.view(np.int16)).view(torch.bfloat16).float().numpy()
-                if dname == "bfloat16" else ref.astype(np.float32))
-        err = float(np.abs(got - want).max())
-        extra["cpu_baseline"]["max_abs_err_gpu_vs_cpu"] = err
+        extra["cpu_baseline"] = cpu_baseline(torch, np, args, w, L, attention_ops)
 
     if dist.rank == 0:
         config = {
-            "workload": f"{desc}: {L} layers x (reshape_and_cache + single_query_cached_kv_attention), "
+            "workload": f"{model_name} decode hot path: {L} layers x (reshape_and_cache + single_query_cached_kv_attention), "
                         f"batch {S} per GPU, {H} heads x {D}, block {B}, ctx {CTX}, "
-                        f"distinct physical blocks, per-layer 2x{cache_bytes / 2 / 2**30:.2f} GiB caches",
+                        f"distinct physical blocks, per-layer 2x{w.cache_bytes / 2 / 2**30:.2f} GiB caches",
             "batch_per_gpu": S, "num_heads": H, "head_size": D, "block_size": B, "context_len": CTX,
-            "layers": L, "sharding": "independent replicas per GPU (no data-path collective)",
+            "layers": L, "sharding": "independent replicas per GPU (no data-path collective); "
+                                     "the head-sharded form is in \"tp\" (N > 1) or under --tp",
         }
-        print(json.dumps(result_line(args, dist.world, elapsed, units, "tokens/s", config, extra)))
+        print(json.dumps(result_line(args, dist.world, elapsed, units, "tokens/s", config, extra,
+                                     metric_text(args, model_name, 1))))
     dist.close()
 
 

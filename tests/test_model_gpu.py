@@ -152,6 +152,112 @@ def test_small_llama_greedy_generation_matches_dense_recompute(pkg):
             assert torch.equal(logits[ids.index(1)], logits[ids.index(3)])
 
 
+def test_opt125m_shaped_greedy_generation_paged_vs_dense(pkg):
+    """OPT-125m's attention shape — 12 heads x 64, hidden 768, learned position
+    embeddings (offset 2), pre-LayerNorm, biased projections, ReLU FFN 3072, tied
+    lm_head; plain PagedAttention without rotary
+    (vllm/model_executor/models/opt.py:38-91, 94-149, 211-229) — two layers with
+    random weights.  Greedy token ids through the paged path (prompt step, then
+    16 decode steps on scattered block tables) against the same weights
+    evaluated densely in fp32 with no cache."""
+    import torch
+    import torch.nn.functional as F
+    from vllm_amd.layers import PagedAttention
+    from vllm_amd.worker import CacheEngine, prepare_inputs, simple_configs
+
+    dtype = torch.float16
+    L, hidden, H, D, ffn, vocab, B, max_pos = 2, 768, 12, 64, 3072, 1000, 16, 128
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+
+    def w(*shape, std):
+        return (torch.randn(*shape, device=DEV, generator=g) * std).to(dtype)
+
+    embed = w(vocab, hidden, std=1.0)
+    pos_embed = w(max_pos + 2, hidden, std=0.3)  # OPTLearnedPositionalEmbedding: rows are position + 2
+    attn = PagedAttention(H, D, D ** -0.5)
+    layers = []
+    for _ in range(L):
+        layers.append(dict(
+            ln1_w=1 + 0.1 * torch.randn(hidden, device=DEV, generator=g), ln1_b=0.1 * torch.randn(hidden, device=DEV, generator=g),
+            ln2_w=1 + 0.1 * torch.randn(hidden, device=DEV, generator=g), ln2_b=0.1 * torch.randn(hidden, device=DEV, generator=g),
+            qkv=w(hidden, 3 * hidden, std=hidden ** -0.5), qkv_b=w(3 * hidden, std=0.1),
+            o=w(hidden, hidden, std=hidden ** -0.5), o_b=w(hidden, std=0.1),
+            fc1=w(hidden, ffn, std=hidden ** -0.5), fc1_b=w(ffn, std=0.1),
+            fc2=w(ffn, hidden, std=ffn ** -0.5), fc2_b=w(hidden, std=0.1)))
+    fin_w = 1 + 0.1 * torch.randn(hidden, device=DEV, generator=g)
+    fin_b = 0.1 * torch.randn(hidden, device=DEV, generator=g)
+    cc, mc, pc = simple_configs(L, H, D, dtype, B, num_gpu_blocks=40, num_cpu_blocks=2)
+    engine = CacheEngine(cc, mc, pc)
+    for kc, vc in engine.gpu_cache:
+        kc.fill_(float("nan"))
+        vc.fill_(float("nan"))
+
+    def ln(x, wt, b):
+        return F.layer_norm(x, (hidden,), wt.to(x.dtype), b.to(x.dtype))
+
+    def paged_forward(tokens, positions, meta):
+        x = embed[tokens] + pos_embed[positions + 2]
+        for i, ly in enumerate(layers):
+            kc, vc = engine.gpu_cache[i]
+            q, k, v = (ln(x, ly["ln1_w"], ly["ln1_b"]) @ ly["qkv"] + ly["qkv_b"]).chunk(3, dim=-1)
+            x = x + attn(q, k, v, kc, vc, meta, None) @ ly["o"] + ly["o_b"]
+            x = x + torch.relu(ln(x, ly["ln2_w"], ly["ln2_b"]) @ ly["fc1"] + ly["fc1_b"]) @ ly["fc2"] + ly["fc2_b"]
+        return ln(x, fin_w, fin_b) @ embed.t()
+
+    def dense_logits(token_ids):
+        n = len(token_ids)
+        t = torch.tensor(token_ids, device=DEV)
+        x = embed[t].float() + pos_embed[torch.arange(n, device=DEV) + 2].float()
+        for ly in layers:
+            q, k, v = (ln(x, ly["ln1_w"], ly["ln1_b"]) @ ly["qkv"].float() + ly["qkv_b"].float()).chunk(3, dim=-1)
+            q, k, v = q.view(n, H, D), k.view(n, H, D), v.view(n, H, D)
+            sc = torch.einsum("qhd,khd->hqk", q, k) * D ** -0.5
+            sc = sc + torch.full((n, n), float("-inf"), device=DEV).triu(1)
+            a = torch.einsum("hqk,khd->qhd", torch.softmax(sc, dim=-1), v).reshape(n, hidden)
+            x = x + a @ ly["o"].float() + ly["o_b"].float()
+            x = x + torch.relu(ln(x, ly["ln2_w"], ly["ln2_b"]) @ ly["fc1"].float() + ly["fc1_b"].float()) @ ly["fc2"].float() \
+                + ly["fc2_b"].float()
+        return ln(x[-1], fin_w, fin_b) @ embed.float().t()
+
+    free_blocks = list(range(39, 0, -1))
+    seqs = {0: SeqData([2, 45, 901, 7]), 1: SeqData(list(range(300, 333))), 2: SeqData([17] * 16), 3: SeqData([5])}
+    tables = {i: [free_blocks.pop() for _ in range((s.get_len() + B - 1) // B)] for i, s in seqs.items()}
+    paged_ids = {i: [] for i in seqs}
+    dense_ids = {i: [] for i in seqs}
+
+    def step(is_prompt):
+        ids = list(seqs)
+        for i in ids:
+            if seqs[i].get_len() > len(tables[i]) * B:
+                tables[i].append(free_blocks.pop())
+        groups = [SimpleNamespace(request_id=str(i), is_prompt=is_prompt, seq_data={i: seqs[i]}, sampling_params=None,
+                                  block_tables={i: tables[i]}) for i in ids]
+        tokens, positions, meta = prepare_inputs(groups, B, device=DEV)
+        logits = paged_forward(tokens, positions, meta)
+        rows, r = [], 0
+        for i in ids:
+            r += seqs[i].get_len() if is_prompt else 1
+            rows.append(r - 1)
+        for row, i in zip(rows, ids):
+            want = dense_logits(seqs[i].tokens)
+            got = logits[row].float()
+            assert torch.allclose(got, want, atol=5e-2, rtol=3e-2), (i, seqs[i].get_len(), float((got - want).abs().max()))
+            top2 = want.topk(2).values
+            tok_ref, tok = int(want.argmax()), int(got.argmax())
+            if float(top2[0] - top2[1]) > 0.15:  # not a near-tie at fp16 resolution of the logits
+                assert tok == tok_ref, (i, seqs[i].get_len())
+                paged_ids[i].append(tok)
+                dense_ids[i].append(tok_ref)
+            seqs[i].tokens.append(tok_ref)
+
+    step(True)
+    for _ in range(16):
+        step(False)
+    assert paged_ids == dense_ids
+    assert sum(len(v) for v in paged_ids.values()) >= 4 * 17 * 0.8, "too many near-ties: the comparison is vacuous"
+
+
 def test_throughput_harness_serves_every_request_on_a_tiny_model(pkg):
     """tools/bench_throughput.py (the reference's offline-throughput benchmark
     restated): continuous batching of mixed prompt + generation steps through
