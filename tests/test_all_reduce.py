@@ -50,9 +50,9 @@ _WORKER = textwrap.dedent("""
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     hidden, shard, max_tokens = 64, 48, 40
-    initialize_all_reduce_launcher(max_tokens, hidden, torch.float32)
+    initialize_all_reduce_launcher(max_tokens, hidden, torch.float32)  # device follows the group's backend: gloo -> CPU
     launcher = get_all_reduce_launcher()
-    assert launcher.disable_graph and launcher.buffer.shape == (max_tokens, hidden)
+    assert launcher.device.type == "cpu" and launcher.disable_graph and launcher.buffer.shape == (max_tokens, hidden)
     g = torch.Generator().manual_seed(7)
     x_full = torch.randn(24, shard * world, generator=g)        # same on every rank
     w_full = torch.randn(shard * world, hidden, generator=g)
@@ -124,7 +124,7 @@ _SHARDED_STEP = textwrap.dedent("""
     case = datagen.DecodeCase(name="tp", dtype="float32", num_seqs=S, num_heads=H, head_size=D, block_size=B,
                               num_blocks=40, max_context=70, dist="normal", tables="forked", fork=3, seed=88)
     lo, hi = head_shard(rank, tp, H)
-    launcher = GraphAllReduce(16, hidden, torch.float32, record_trace=True)
+    launcher = GraphAllReduce(16, hidden, torch.float32, device="cpu", record_trace=True)
     step = TensorParallelDecodeStep(rank, tp, H, D, D ** -0.5, launcher, attention_ops=OracleOps, cache_ops=OracleOps)
     g = torch.Generator().manual_seed(3)
     w_o = torch.randn(L, H * D, hidden, generator=g) * (H * D) ** -0.5

@@ -77,7 +77,9 @@ class GraphAllReduce:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            # the group's backend decides where its tensors live: RCCL ("nccl") sums device memory, gloo host memory
+            on_gpu = torch.cuda.is_available() and (not dist.is_initialized() or dist.get_backend(group) == "nccl")
+            device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"
         self.disable_graph = disable_graph or not self.on_gpu
