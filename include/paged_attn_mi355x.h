@@ -93,7 +93,8 @@ int pa_single_query_cached_kv_attention(
  * at least pa_decode_workspace_bytes(...) bytes (device memory, 8-byte
  * aligned, contents irrelevant, may be reused by the next call on the same
  * stream) the library may split every sequence's context into partitions that
- * run as separate workgroups and are combined by a second kernel; it does so
+ * run as separate workgroups; the partition of a row that finishes last
+ * combines them inside the same launch.  It does so
  * when num_seqs * num_heads alone cannot fill the GPU (small batches), and for
  * big batches whose longest context exceeds 1024 tokens (there, the partitions
  * that exist are listed on the device first, so that one long sequence among
@@ -127,10 +128,14 @@ int pa_single_query_cached_kv_attention_ws(
  * The first call of a step passes plan_ready = 0 and makes the plan; the
  * others pass plan_ready = 1 with the SAME workspace, num_seqs, num_heads,
  * head_size, block_size, max_context_len and an unchanged context_lens, and
- * skip that kernel.  The rest of the workspace is scratch as above.  The plan
+ * skip that kernel.  The rest of the workspace is scratch as above (the rows'
+ * ticket words of the partitioned forms are part of the plan: made zero with
+ * it, and zero again at the end of every launch).  The plan
  * carries a stamp of the sizes it was made for: with a workspace whose plan
- * was never made, or made for other sizes, the call writes nothing at all.  A
- * plan made from other context_lens of the same sizes gives wrong results.  pa_single_query_cached_kv_attention_ws makes the
+ * was never made, or made for other sizes, the call fills `out` with NaN
+ * instead of computing anything, so that the caller's error cannot pass for a
+ * result.  A plan made from other context_lens of the same sizes gives wrong
+ * results.  pa_single_query_cached_kv_attention_ws makes the
  * plan on every call, and makes the row order only for launches big enough to
  * win it back.  total_context_len is the sum of context_lens if the caller
  * knows it on the host (the engine builds context_lens from a host list), else

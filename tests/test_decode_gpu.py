@@ -60,10 +60,11 @@ def test_partition_plan_splits_small_batches_only(pkg):
     # too few sequences to balance, contexts too short to split
     assert c.decode_workspace_bytes(40, 32, 128, 16, 1024) == 0
     # one sequence: 32 rows -> split into partitions of at least 64 tokens / 4 blocks
-    n = c.decode_workspace_bytes(1, 32, 128, 16, 1024)
+    # (accumulator + max + sum per row and partition, then a stamp and one ticket word per row)
+    n = c.decode_workspace_bytes(1, 32, 128, 16, 1024) - (32 + 1) * 4
     assert n > 0 and n % ((128 + 2) * 4 * 32) == 0
     parts = n // ((128 + 2) * 4 * 32)
-    assert 2 <= parts <= 16
+    assert 2 <= parts <= 32
     # a context that is a single partition long is never split
     assert c.decode_workspace_bytes(1, 1, 64, 16, 64) == 0
     assert c.decode_workspace_bytes(0, 32, 128, 16, 1024) == 0
@@ -541,11 +542,12 @@ def test_decode_step_replays_from_a_hip_graph(pkg):
 
 
 @pytest.mark.parametrize("longest", [300, 2600], ids=["rows", "item_list"])
-def test_decode_with_a_workspace_that_holds_no_plan_writes_nothing(pkg, longest):
+def test_decode_with_a_workspace_that_holds_no_plan_poisons_the_output(pkg, longest):
     """plan_ready=True on a workspace whose plan was never made (arbitrary
     bytes), or was made for another batch size: every workgroup sees that the
-    stamp does not match and leaves; `out` keeps its contents.  The same
-    workspace then serves a proper pair of calls."""
+    stamp does not match, computes nothing and fills `out` with NaN, so the
+    caller's error cannot pass for a result.  The same workspace then serves a
+    proper pair of calls."""
     import torch
     rng = np.random.default_rng(8)
     H, D, B = 8, 64, 16
@@ -566,7 +568,7 @@ def test_decode_with_a_workspace_that_holds_no_plan_writes_nothing(pkg, longest)
         pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
                                                            ws[:nbytes // 4], True)
         torch.cuda.synchronize()
-        assert bool((out == 7.0).all()), f"S={S}: a call without a valid plan wrote to out"
+        assert bool(torch.isnan(out.float()).all()), f"S={S}: a call without a valid plan left values in out"
         ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
             inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
             inp["context_lens"], case.dtype), case.dtype)
@@ -725,3 +727,50 @@ def test_decode_opt125m_microbench_size_properties(pkg):
                 np.array([ctx_list[s]], dtype=np.int32), "float16")
             helpers.assert_close(out[s].float().cpu().numpy(), ref.astype(np.float32)[0], 2e-5, 1.5e-3,
                                  f"microbench shape, {form}, sequence {s}")
+
+
+@pytest.mark.parametrize("dtype", ["float16", "float32"])
+def test_decode_uniform_partitions_combined_by_the_last_partition_of_a_row(pkg, dtype):
+    """Few rows: every row is cut into partitions, and the partition of a row
+    that finishes last combines them in the same launch, counted by a ticket
+    word per row that is zeroed with the plan and put back to zero by the
+    combiner.  Several layers on one plan (plan_ready False, then True) on a
+    workspace that starts as NaN bytes; rows of zero, one and many partitions;
+    then a smaller batch planned into the same workspace; and plan_ready=True
+    on a workspace planned for other sizes fills the output with NaN."""
+    import torch
+    H, D, B = 4, 128, 16
+    atol, rtol = helpers.TIGHT[dtype]
+    ws = None
+    for ctx in ([1500, 0, 17, 900, 64, 65, 2047], [700, 3]):
+        S, longest = len(ctx), max(ctx)
+        nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
+        assert nbytes > (S * H + 1) * 4
+        if ws is None:
+            ws = torch.full((nbytes // 4 + 8,), float("nan"), dtype=torch.float32, device="cuda:0")
+        else:
+            # the plan in the workspace is the bigger batch's: a call that claims it is ready gets NaN
+            case = datagen.DecodeCase(name="stale", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                                      num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                      tables="permutation", seed=650)
+            inp = datagen.make_decode_inputs(case)
+            qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
+            out = torch.full((S, H, D), 3.0, dtype=qkv.dtype, device="cuda:0")
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
+                                                               ws[:nbytes // 4], True)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(out.float()).all())
+        for layer in range(4):
+            case = datagen.DecodeCase(name="parts", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                                      num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                      tables="permutation", seed=660 + layer)
+            inp = datagen.make_decode_inputs(case)
+            qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
+            out = torch.full((S, H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
+                                                               ws[:nbytes // 4], layer > 0)
+            torch.cuda.synchronize()
+            helpers.assert_close(helpers.out_to_f32(out, dtype), _oracle_f32(inp, case), atol, 2 * rtol,
+                                 f"S={S} layer {layer}")
+            tickets = ws[:nbytes // 4].view(torch.int32)[-(S * H):]
+            assert int(tickets.abs().sum()) == 0, "a row's ticket word did not return to zero"

@@ -173,8 +173,8 @@ def test_opt125m_shaped_greedy_generation_paged_vs_dense(pkg):
     def w(*shape, std):
         return (torch.randn(*shape, device=DEV, generator=g) * std).to(dtype)
 
-    embed = w(vocab, hidden, std=1.0)
-    pos_embed = w(max_pos + 2, hidden, std=0.3)  # OPTLearnedPositionalEmbedding: rows are position + 2
+    embed = w(vocab, hidden, std=0.1)  # tied lm_head: logits of a layer-normed row then have a spread of about 3
+    pos_embed = w(max_pos + 2, hidden, std=0.03)  # OPTLearnedPositionalEmbedding: rows are position + 2
     attn = PagedAttention(H, D, D ** -0.5)
     layers = []
     for _ in range(L):
