@@ -93,10 +93,10 @@ int pa_single_query_cached_kv_attention(
  * at least pa_decode_workspace_bytes(...) bytes (device memory, 8-byte
  * aligned, contents irrelevant, may be reused by the next call on the same
  * stream) the library may split every sequence's context into partitions that
- * run as separate workgroups; the partition of a row that finishes last
- * combines them inside the same launch.  It does so
+ * run as separate workgroups and are combined by a second kernel; it does so
  * when num_seqs * num_heads alone cannot fill the GPU (small batches), and for
- * big batches whose longest context exceeds 1024 tokens (there, the partitions
+ * big batches whose longest context exceeds one partition of 256 to 1024 tokens
+ * (the more rows, the longer; there, the partitions
  * that exist are listed on the device first, so that one long sequence among
  * short ones does not set the launch time alone).  With
  * workspace == NULL, or one that is too small, it behaves exactly like
@@ -128,9 +128,7 @@ int pa_single_query_cached_kv_attention_ws(
  * The first call of a step passes plan_ready = 0 and makes the plan; the
  * others pass plan_ready = 1 with the SAME workspace, num_seqs, num_heads,
  * head_size, block_size, max_context_len and an unchanged context_lens, and
- * skip that kernel.  The rest of the workspace is scratch as above (the rows'
- * ticket words of the partitioned forms are part of the plan: made zero with
- * it, and zero again at the end of every launch).  The plan
+ * skip that kernel.  The rest of the workspace is scratch as above.  The plan
  * carries a stamp of the sizes it was made for: with a workspace whose plan
  * was never made, or made for other sizes, the call fills `out` with NaN
  * instead of computing anything, so that the caller's error cannot pass for a
@@ -141,8 +139,10 @@ int pa_single_query_cached_kv_attention_ws(
  * knows it on the host (the engine builds context_lens from a host list), else
  * -1: with it the library can tell on the host that no sequence of a big batch
  * is long enough to need partitions, and leaves that machinery out of the
- * launch.  It must be the same for all calls on one plan.  No counterpart in
- * the reference.
+ * launch, and reserves workgroup ids only for as many partitions as that sum
+ * allows.  It must be the same for all calls on one plan, and it must not be
+ * less than the true sum: if the device finds more partitions than were
+ * reserved, `out` is filled with NaN.  No counterpart in the reference.
  */
 int pa_single_query_cached_kv_attention_planned(
     void* out, const void* query, const void* key_cache, const void* value_cache,

@@ -58,13 +58,15 @@ def test_partition_plan_splits_small_batches_only(pkg):
     # balanced order (8 XCDs x 32 sequences x 8 bytes, and a stamp)
     assert c.decode_workspace_bytes(256, 32, 128, 16, 1024) == (8 * 32 + 1) * 8
     # too few sequences to balance, contexts too short to split
-    assert c.decode_workspace_bytes(40, 32, 128, 16, 1024) == 0
+    assert c.decode_workspace_bytes(40, 32, 128, 16, 256) == 0
+    # 1280 rows with contexts of several 256-token partitions: partial results for up to 4 partitions per row
+    n = c.decode_workspace_bytes(40, 32, 128, 16, 1024)
+    assert n >= 40 * 32 * 4 * (128 + 2) * 4
     # one sequence: 32 rows -> split into partitions of at least 64 tokens / 4 blocks
-    # (accumulator + max + sum per row and partition, then a stamp and one ticket word per row)
-    n = c.decode_workspace_bytes(1, 32, 128, 16, 1024) - (32 + 1) * 4
+    n = c.decode_workspace_bytes(1, 32, 128, 16, 1024)
     assert n > 0 and n % ((128 + 2) * 4 * 32) == 0
     parts = n // ((128 + 2) * 4 * 32)
-    assert 2 <= parts <= 32
+    assert 2 <= parts <= 16
     # a context that is a single partition long is never split
     assert c.decode_workspace_bytes(1, 1, 64, 16, 64) == 0
     assert c.decode_workspace_bytes(0, 32, 128, 16, 1024) == 0
@@ -305,8 +307,9 @@ def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype, reps):
     """More than 256 rows and a longest context beyond 2048 tokens: the library
     lists the non-empty (sequence, partition) pairs on the device and a
     fixed-size grid draws from the list.  Mixed lengths on both sides of the
-    1024-token partition edge, empty contexts, one long outlier; also with an
-    understated max_context_len (the last partition must run to the end)."""
+    partition edges, empty contexts, one long outlier; also with an
+    understated max_context_len (the last partition must run to the end), and with the
+    sum of the context lengths given (fewer workgroup ids reserved for partitions)."""
     import torch
     ctx = [5000, 100, 2049, 1024, 1025, 0, 1, 16, 2048, 3000, 1023, 77] * reps + [4097]
     S, H, D, B = len(ctx), 8, 64, 16  # 16 units of 4 sequences and more take the balanced order
@@ -325,6 +328,22 @@ def test_decode_item_list_mode_on_a_long_mixed_batch(pkg, dtype, reps):
         for _ in range(2):  # twice on one workspace: the plan kernel rewinds the counters
             got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=True), dtype)
             helpers.assert_close(got, ref, atol, 2 * rtol, f"item list, announced {announced}")
+    # with the sum of the context lengths: workgroup ids are reserved for as many partitions as
+    # that sum allows, not for the worst case; a sum that is too small is caught on the device
+    inp["max_context_len"] = max(ctx)
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, max(ctx))
+    ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda:0")
+    for total, good in ((sum(ctx), True), (sum(ctx) // 8, False)):
+        for ready in (False, True):
+            out = torch.full((S, H, D), 2.0, dtype=qkv.dtype, device="cuda:0")
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, max(ctx), ws,
+                                                               ready, total)
+            torch.cuda.synchronize()
+            if good:
+                helpers.assert_close(helpers.out_to_f32(out, dtype), ref, atol, 2 * rtol, f"total given, ready={ready}")
+            else:
+                assert bool(torch.isnan(out.float()).all()), "an understated total_context_len passed for a result"
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -402,8 +421,10 @@ def test_decode_item_list_plan_splits_only_rows_that_would_hold_up_the_launch(pk
         plan = view.view(torch.int32)[-3:].tolist()
         if split_expected:
             bpp = plan[2]
-            assert bpp * B >= 1024 and bpp < (1 << 24), name
-            assert plan[1] == sum(min((c + bpp * B - 1) // (bpp * B), 4) - 1 for c in ctx), name
+            assert bpp * B >= 256 and bpp < (1 << 24), name
+            most = ((max(ctx) + B - 1) // B + bpp - 1) // bpp  # partitions of the longest context the plan allows for
+            assert 2 <= most <= 16, name
+            assert plan[1] == sum(min((c + bpp * B - 1) // (bpp * B), most) - 1 for c in ctx), name
             assert plan[1] > 0, name
         else:
             assert plan[1] == 0 and plan[2] == 1 << 24, name
@@ -727,50 +748,3 @@ def test_decode_opt125m_microbench_size_properties(pkg):
                 np.array([ctx_list[s]], dtype=np.int32), "float16")
             helpers.assert_close(out[s].float().cpu().numpy(), ref.astype(np.float32)[0], 2e-5, 1.5e-3,
                                  f"microbench shape, {form}, sequence {s}")
-
-
-@pytest.mark.parametrize("dtype", ["float16", "float32"])
-def test_decode_uniform_partitions_combined_by_the_last_partition_of_a_row(pkg, dtype):
-    """Few rows: every row is cut into partitions, and the partition of a row
-    that finishes last combines them in the same launch, counted by a ticket
-    word per row that is zeroed with the plan and put back to zero by the
-    combiner.  Several layers on one plan (plan_ready False, then True) on a
-    workspace that starts as NaN bytes; rows of zero, one and many partitions;
-    then a smaller batch planned into the same workspace; and plan_ready=True
-    on a workspace planned for other sizes fills the output with NaN."""
-    import torch
-    H, D, B = 4, 128, 16
-    atol, rtol = helpers.TIGHT[dtype]
-    ws = None
-    for ctx in ([1500, 0, 17, 900, 64, 65, 2047], [700, 3]):
-        S, longest = len(ctx), max(ctx)
-        nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
-        assert nbytes > (S * H + 1) * 4
-        if ws is None:
-            ws = torch.full((nbytes // 4 + 8,), float("nan"), dtype=torch.float32, device="cuda:0")
-        else:
-            # the plan in the workspace is the bigger batch's: a call that claims it is ready gets NaN
-            case = datagen.DecodeCase(name="stale", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
-                                      num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
-                                      tables="permutation", seed=650)
-            inp = datagen.make_decode_inputs(case)
-            qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
-            out = torch.full((S, H, D), 3.0, dtype=qkv.dtype, device="cuda:0")
-            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
-                                                               ws[:nbytes // 4], True)
-            torch.cuda.synchronize()
-            assert bool(torch.isnan(out.float()).all())
-        for layer in range(4):
-            case = datagen.DecodeCase(name="parts", dtype=dtype, num_seqs=S, num_heads=H, head_size=D, block_size=B,
-                                      num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
-                                      tables="permutation", seed=660 + layer)
-            inp = datagen.make_decode_inputs(case)
-            qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, dtype, "cuda:0")
-            out = torch.full((S, H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
-            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
-                                                               ws[:nbytes // 4], layer > 0)
-            torch.cuda.synchronize()
-            helpers.assert_close(helpers.out_to_f32(out, dtype), _oracle_f32(inp, case), atol, 2 * rtol,
-                                 f"S={S} layer {layer}")
-            tickets = ws[:nbytes // 4].view(torch.int32)[-(S * H):]
-            assert int(tickets.abs().sum()) == 0, "a row's ticket word did not return to zero"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Sweeps decode-attention shapes on one GPU and prints achieved HBM GB/s
-(algorithmic bytes / mean launch time).  Small working sets are rotated over
+(algorithmic bytes / mean launch time; for batches whose sequences share
+physical blocks, the distinct bytes).  Small working sets are rotated over
 several cache copies so that the 256 MiB Infinity Cache cannot serve them.
 
     python tools/sweep_decode.py [--only NAME_SUBSTR] [--json out.json]
@@ -168,15 +169,25 @@ def run(cfg, pkg, device, launches=30):
     ts = sorted(a.elapsed_time(b) / per_group for a, b in evs)
     mean = sum(ts) / len(ts)
     nbytes = algorithmic_bytes(ctxs, H, D, B, es)
+    if half:
+        # Shared-prefix batch: the algorithmic figure counts a shared block once per reader, but
+        # only its first reader brings it from HBM.  The roofline fraction is priced on the bytes
+        # that are distinct: shared tokens once per group, own tokens once per sequence.
+        shared_tokens = groups * half * B
+        own_tokens = sum(max(c - half * B, 0) for c in ctxs)
+        nbytes_unique = nbytes - sum(ctxs) * H * 2 * D * es + (shared_tokens + own_tokens) * H * 2 * D * es
+    else:
+        nbytes_unique = nbytes
     del kcs, vcs
     torch.cuda.empty_cache()
-    return dict(cfg, us_mean=mean * 1e3, us_min=ts[0] * 1e3, gbps=nbytes / (mean * 1e-3) / 1e9,
-                mbytes=nbytes / 1e6, copies=copies)
+    return dict(cfg, us_mean=mean * 1e3, us_min=ts[0] * 1e3, gbps=nbytes_unique / (mean * 1e-3) / 1e9,
+                mbytes=nbytes_unique / 1e6, copies=copies, gbps_per_reader=nbytes / (mean * 1e-3) / 1e9)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--names", default="", help="comma-separated exact configuration names")
     ap.add_argument("--json", default="")
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--sequential", action="store_true")
@@ -192,11 +203,15 @@ def main():
     for cfg in configs():
         if args.only and args.only not in cfg["name"]:
             continue
+        if args.names and cfg["name"] not in args.names.split(","):
+            continue
         r = run(cfg, pkg, device)
         rows.append(r)
         print(f"{r['name']:24s} S={r['S']:<4d} H={r['H']:<3d} D={r['D']:<4d} B={r['B']:<3d} ctx={r['ctx']:<5d} "
               f"{r['dt']:4s} {r['mbytes']:9.1f} MB  {r['us_mean']:9.1f} us (min {r['us_min']:8.1f})  "
-              f"{r['gbps']:7.0f} GB/s  {100 * r['gbps'] / 8000:5.1f}% of 8 TB/s", flush=True)
+              f"{r['gbps']:7.0f} GB/s  {100 * r['gbps'] / 8000:5.1f}% of 8 TB/s"
+              + (f"  (distinct bytes; {r['gbps_per_reader']:.0f} GB/s counted per reader)" if r["share"] > 1 else ""),
+              flush=True)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)

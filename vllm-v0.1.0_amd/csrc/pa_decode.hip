@@ -187,11 +187,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //   writes the normalised output row.
 // kModeParts: one workgroup per (sequence, head, partition) walks
 //   blocks_per_part KV blocks and writes its un-normalised (max, sum,
-//   accumulator) triple to a workspace; the partition of a row that finishes
-//   LAST combines them and writes the output row (see "hand-off" at the end of
-//   the kernel) — no second launch.  Every sequence gets the same number of
-//   partitions (the empty ones exit at once): for few sequences, where the chip
-//   is otherwise idle.
+//   accumulator) triple to a workspace; pa_decode_merge_kernel combines the
+//   partitions.  Every sequence gets the same number of partitions (the empty
+//   ones exit at once): for few sequences, where the chip is otherwise idle.
 // kModeList : for big batches with long contexts.  Partitions of a fixed
 //   length, as many as each sequence needs (at most four).  Every row's first
 //   partition has a workgroup of its own, as in kModeRows;
@@ -199,8 +197,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //   exist from context_lens, and the grid carries one slot per pair that COULD
 //   exist, ahead of the rows: a slot past the end of the list costs one scalar
 //   load.  A sequence of one partition gets its output row written directly,
-//   longer ones go through the workspace and are combined by their last
-//   partition to finish.  One long
+//   longer ones go through the workspace and the merge kernel.  One long
 //   sequence among short ones is thereby spread over several workgroups that
 //   start first, instead of setting the launch time alone.  The plan kernel
 //   may also find that no sequence needs a second partition (see there).
@@ -235,62 +232,18 @@ struct DecodeArgs {
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [0] the plan's stamp, [1] number of pairs, [2] blocks per partition in force
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
-  // partitioned forms: [0] the plan's stamp, [1 + row] how many partitions of the row have finished.
-  // Zeroed when the plan is made; the partition that draws the last ticket of a row puts its word
-  // back to 0, so the words are zero again when the launch ends (every layer of a step reuses them).
-  unsigned* merge_cnt;
 };
 
 // A launch that finds no plan for its sizes in the workspace (never made, or made for another
 // batch) must not pass for a result: every output row is filled with NaN instead.  The grid of
 // every launch form has at least one workgroup per row.
-template <typename E, int D>
-__device__ __forceinline__ void poison_output_row(const DecodeArgs& a) {
+template <typename E, int D, typename Args>
+__device__ __forceinline__ void poison_output_row(const Args& a) {
   typedef typename E::storage T;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
   if (blockIdx.x >= rows) return;
   T* op = static_cast<T*>(a.out) + (int64_t)blockIdx.x * D;
   for (int d = threadIdx.x; d < D; d += blockDim.x) op[d] = E::from_float(__builtin_nanf(""));
-}
-
-// Combines the finished partitions of one (sequence, head) row: run by the workgroup that drew
-// the row's last ticket, after its acquire.  Wave w sums columns d = 64 w + lane; the (max, sum)
-// pairs are read one partition per lane and reduced across the wave, the accumulator rows with
-// all loads of a group of eight partitions issued before the first use.  Every load of the
-// partitions' data has a per-lane address: handed-off bytes stay off the scalar cache.
-template <typename E, int D>
-__device__ __forceinline__ void merge_partitions(const DecodeArgs& a, int64_t row, int nparts, int lane, int wave) {
-  typedef typename E::storage T;
-  if (wave * 64 >= D) return;
-  const int d = wave * 64 + lane;
-  const float* ml = a.ws_ml + 2 * row * a.num_parts;
-  const float* wacc = a.ws_acc + row * a.num_parts * D;
-  float mg = -FLT_MAX;
-  for (int p0 = 0; p0 < nparts; p0 += 64) {
-    const int p = p0 + lane;
-    float mp = p < nparts ? ml[2 * p] : -FLT_MAX;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mp = fmaxf(mp, __shfl_xor(mp, off));
-    mg = fmaxf(mg, mp);
-  }
-  float o = 0.f, L = 0.f;
-  for (int p0 = 0; p0 < nparts; p0 += 64) {
-    const int p = p0 + lane;
-    const float fp = p < nparts ? fast_exp2(ml[2 * p] - mg) : 0.f;
-    float lp = p < nparts ? ml[2 * p + 1] * fp : 0.f;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lp += __shfl_xor(lp, off);
-    L += lp;
-    const int n = min(64, nparts - p0);
-    for (int k0 = 0; k0 < n; k0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = (k0 + k < n && d < D) ? wacc[(int64_t)(p0 + k0 + k) * D + d] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; k++) o = __builtin_fmaf(v[k], __shfl(fp, (k0 + k) & 63), o);
-    }
-  }
-  if (d < D) static_cast<T*>(a.out)[row * D + d] = E::from_float(o * (1.f / (L + 1e-6f)));
 }
 
 // Build-time knob for A/B runs: 1 = stream every K/V tile with the
@@ -363,12 +316,16 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   int part = 0;
   if (MODE == kModeList) {
     // a workspace whose plan was never made, or made for other sizes
-    if (a.counters[0] != a.plan_tag || a.merge_cnt[0] != a.plan_tag) {
+    if (a.counters[0] != a.plan_tag) {
+      poison_output_row<E, D>(a);
+      return;
+    }
+    const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
+    if (n_items > a.list_slots) {  // more pairs than the caller's total_context_len allows for: it was not the sum
       poison_output_row<E, D>(a);
       return;
     }
     if (blockIdx.x < a.list_slots) {
-      const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
       if (blockIdx.x >= n_items) return;  // unused slot: one scalar load, then gone
       // heads fastest: the heads of a pair spread over the XCDs, whose shares of the listed work
       // are thereby equal (an XCD walking whole pairs measured the same on random lengths)
@@ -388,10 +345,6 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   const unsigned per_group = G * (unsigned)a.num_heads;
   // kModeList: the partition length in force is the plan kernel's decision
   const int bpp = MODE == kModeList ? (int)a.counters[2] : a.blocks_per_part;
-  if (MODE == kModeParts && a.merge_cnt[0] != a.plan_tag) {  // no plan for these sizes in the workspace
-    poison_output_row<E, D>(a);
-    return;
-  }
   int head, seq, ctx;
   if (listed) {
     head = head_l;
@@ -455,15 +408,13 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 
   // never beyond the table's width (a plan made from other context_lens may say more)
   const int nblk_seq = min((ctx + B - 1) / B, a.max_blocks_per_seq);
-  // partitions this row has (the last one runs to the end of the context); a row of one
-  // partition is finished here, without the workspace
-  const int nparts_row = PART ? min((nblk_seq + bpp - 1) / bpp, a.num_parts) : 1;
-  const bool direct = nparts_row <= 1;
+  // kModeList: a sequence that fits one partition is finished here, without the workspace
+  const bool direct = !PART || (MODE == kModeList && nblk_seq <= bpp);
   const int blk_begin = PART ? part * bpp : 0;
   // the last partition runs to the end of the context even if the context is
   // longer than the max_context_len the partition plan was made for
   const int nblk = (PART && part + 1 < a.num_parts) ? min(nblk_seq, blk_begin + bpp) : nblk_seq;
-  if (MODE == kModeParts && part > 0 && blk_begin >= nblk) return;  // empty partition: it draws no ticket
+  if (MODE == kModeParts && blk_begin >= nblk) return;  // empty partition: the merge kernel never reads it
   const int* __restrict__ table = a.block_tables + (int64_t)seq * a.max_blocks_per_seq;
   // Neighbouring sequences' tables, to spot shared physical blocks (forked
   // sequences keep the parent's blocks and sit next to it in the batch).
@@ -683,7 +634,19 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     L = __builtin_fmaf(part_l[w], f[w], L);
   }
   const int64_t row = (int64_t)seq * a.num_heads + head;
-  if (direct) {
+  if (!direct) {
+    const int64_t slot = row * a.num_parts + part;
+    for (int d = tid; d < D; d += NW * 64) {
+      float o = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; w++) o = __builtin_fmaf(part_acc[w][d], f[w], o);
+      a.ws_acc[slot * D + d] = o;
+    }
+    if (tid == 0) {
+      a.ws_ml[2 * slot] = mg;
+      a.ws_ml[2 * slot + 1] = L;
+    }
+  } else {
     T* op = static_cast<T*>(a.out) + row * D;
     const float inv = 1.f / (L + 1e-6f);
     for (int d = tid; d < D; d += NW * 64) {
@@ -692,44 +655,11 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
       for (int w = 0; w < NW; w++) o = __builtin_fmaf(part_acc[w][d], f[w], o);
       op[d] = E::from_float(o * inv);
     }
-    return;
   }
-  // ---- hand-off: this partition's triple goes to the workspace; the last one of the row combines ----
-  // Another workgroup, possibly on another XCD (its own L2), will read these words inside this
-  // launch: they are stored write-through at agent scope, every wave drains its stores, and only
-  // then does one lane draw the row's ticket.
-  const int64_t slot = row * a.num_parts + part;
-  for (int d = tid; d < D; d += NW * 64) {
-    float o = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; w++) o = __builtin_fmaf(part_acc[w][d], f[w], o);
-    __hip_atomic_store(&a.ws_acc[slot * D + d], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (tid == 0) {
-    __hip_atomic_store(&a.ws_ml[2 * slot], mg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&a.ws_ml[2 * slot + 1], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // also: every thread has read part_m / part_l
-  if (tid == 0) {
-    unsigned* cnt = a.merge_cnt + 1 + row;
-    const unsigned arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const bool last = arrived == (unsigned)nparts_row;
-    if (last) {
-      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this plan
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    part_l[0] = last ? 1.f : 0.f;
-  }
-  __syncthreads();
-  if (part_l[0] == 0.f) return;
-  merge_partitions<E, D>(a, row, nparts_row, lane, wave);
 }
 
 // Plans one launch from context_lens: one workgroup of kPlanThreads.
 //
-// 0. (partitioned forms) Zeroes the rows' ticket words and stamps them.
 // 1. (item-list form) Whether to split at all.  Partitions exist to keep one
 //    long sequence from setting the launch time alone.  A row workgroup shares
 //    the GPU with resident_slots - 1 others, so the longest row, which starts
@@ -770,9 +700,7 @@ struct PlanArgs {
   int2* row_table;      // null = no balanced order
   int unit;
   int slots_per_xcd;
-  unsigned tag;         // stamped on the item list (counters[0]), behind the row table and on merge_cnt[0]
-  unsigned* merge_cnt;  // partitioned forms: [0] stamp, [1 + row] tickets, zeroed here; null = no partitions
-  unsigned num_rows;
+  unsigned tag;         // stamped on the item list (counters[0]) and behind the row table
 };
 
 // number of keys in [lo, lo + span) among keys[0 .. n), n a multiple of 4 (padding keys are 0 and lo > 0)
@@ -797,8 +725,6 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
   __shared__ int table[kMaxTableSlots];
   const int tid = threadIdx.x, nthreads = blockDim.x;  // nthreads: a power of two
   const int num_seqs = p.num_seqs, block_size = p.block_size;
-  if (p.merge_cnt != nullptr)
-    for (unsigned i = tid; i <= p.num_rows; i += nthreads) p.merge_cnt[i] = i == 0 ? p.tag : 0u;
   int bpp = kNoSplitBlocks;
   if (p.max_parts > 1) {
     unsigned long long total = 0;
@@ -919,6 +845,76 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
   if (tid == 0) p.row_table[8 * NX] = make_int2((int)p.tag, (int)~p.tag);
 }
 
+// Combines the partitions of one (sequence, head): one wave per output row.
+// The (max, sum) pairs are read one partition per lane and reduced across the
+// wave; the accumulator rows are then summed with lanes along d, all loads of
+// a group of partitions issued before the first use.
+template <typename E, int D>
+__global__ void __launch_bounds__(64)
+pa_decode_merge_kernel(const DecodeArgs a, const int planned_tokens_per_part, const int block_size,
+                       const int skip_single) {
+  typedef typename E::storage T;
+  constexpr int PER = (D + 63) / 64;
+  const int lane = threadIdx.x;
+  const int64_t row = blockIdx.x;  // seq * num_heads + head
+  const int seq = (int)(row / a.num_heads);
+  const int ctx = a.context_lens[seq];
+  // kModeList (skip_single): the partition length is the plan kernel's
+  // no plan for these sizes in the workspace, or more listed pairs than slots: the decode kernel poisoned the output
+  if (skip_single && (a.counters[0] != a.plan_tag || a.counters[1] * (unsigned)a.num_heads > a.list_slots)) return;
+  const int tokens_per_part = skip_single ? (int)a.counters[2] * block_size : planned_tokens_per_part;
+  const int nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
+  if (skip_single && nparts <= 1) return;  // kModeList wrote this row directly
+  const float* __restrict__ ml = a.ws_ml + 2 * row * a.num_parts;
+  const float* __restrict__ wacc = a.ws_acc + row * a.num_parts * D;
+
+  float mg = -FLT_MAX;
+  for (int p0 = 0; p0 < nparts; p0 += 64) {
+    const int p = p0 + lane;
+    float mp = p < nparts ? ml[2 * p] : -FLT_MAX;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mp = fmaxf(mp, __shfl_xor(mp, off));
+    mg = fmaxf(mg, mp);
+  }
+  float o[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) o[i] = 0.f;
+  float L = 0.f;
+  for (int p0 = 0; p0 < nparts; p0 += 64) {
+    const int p = p0 + lane;
+    const float fp = p < nparts ? fast_exp2(ml[2 * p] - mg) : 0.f;
+    float lp = p < nparts ? ml[2 * p + 1] * fp : 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lp += __shfl_xor(lp, off);
+    L += lp;
+    const int n = min(64, nparts - p0);
+    for (int k0 = 0; k0 < n; k0 += 8) {
+      float v[8][PER];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+          const int d = lane + 64 * i;
+          v[k][i] = (k0 + k < n && d < D) ? wacc[(int64_t)(p0 + k0 + k) * D + d] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const float f = __shfl(fp, (k0 + k) & 63);
+#pragma unroll
+        for (int i = 0; i < PER; i++) o[i] = __builtin_fmaf(v[k][i], f, o[i]);
+      }
+    }
+  }
+  const float inv = 1.f / (L + 1e-6f);
+  T* op = static_cast<T*>(a.out) + row * D;
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    const int d = lane + 64 * i;
+    if (d < D) op[d] = E::from_float(o[i] * inv);
+  }
+}
+
 // ---- host side ----------------------------------------------------------------
 
 constexpr int kNumWaves = 4;
@@ -954,14 +950,13 @@ static int resident_slots(int head_size) {
 }
 
 template <typename E, int D, int B>
-static int launch(const DecodeArgs& a, bool plan_ready, hipStream_t stream) {
+static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hipStream_t stream) {
   constexpr int NW = D <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
   // workgroups of the row pass: in the balanced order every XCD gets slots_per_xcd sequences' worth
   const unsigned row_wgs = a.row_table != nullptr ? 8u * (unsigned)a.slots_per_xcd * (unsigned)a.num_heads : rows;
-  const bool parts = a.num_parts > 1;
-  const bool list = parts && a.items != nullptr;
-  if ((parts || a.row_table != nullptr) && !plan_ready) {
+  const bool list = a.num_parts > 1 && a.items != nullptr;
+  if ((list || a.row_table != nullptr) && !plan_ready) {
     PlanArgs p;
     p.context_lens = a.context_lens;
     p.num_seqs = a.num_seqs;
@@ -977,45 +972,47 @@ static int launch(const DecodeArgs& a, bool plan_ready, hipStream_t stream) {
     p.unit = a.unit;
     p.slots_per_xcd = a.slots_per_xcd;
     p.tag = a.plan_tag;
-    p.merge_cnt = parts ? a.merge_cnt : nullptr;
-    p.num_rows = rows;
     int plan_threads = 256;  // a power of two; the balanced order wants one thread per sequence
     while (plan_threads < kPlanThreads && plan_threads < a.num_seqs) plan_threads *= 2;
     hipLaunchKernelGGL(pa_decode_plan_kernel, dim3(1), dim3(plan_threads), 0, stream, p);
     PA_CHECK_LAUNCH("pa_decode_plan_kernel launch");
   }
-  if (!parts) {
+  if (a.num_parts <= 1) {
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeRows>), dim3(row_wgs), dim3(NW * 64), 0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel launch");
   } else if (!list) {
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeParts>), dim3(rows * (unsigned)a.num_parts), dim3(NW * 64),
                        0, stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (partitioned) launch");
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 0);
+    PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   } else {
     hipLaunchKernelGGL((pa_decode_kernel<E, D, B, NW, kModeList>), dim3(a.list_slots + row_wgs), dim3(NW * 64), 0,
                        stream, a);
     PA_CHECK_LAUNCH("pa_decode_kernel (item list) launch");
+    hipLaunchKernelGGL((pa_decode_merge_kernel<E, D>), dim3(rows), dim3(64), 0, stream, a, tokens_per_part, B, 1);
+    PA_CHECK_LAUNCH("pa_decode_merge_kernel launch");
   }
   return PA_OK;
 }
 
 template <typename E, int D>
-static int dispatch_block(int B, const DecodeArgs& a, bool plan_ready, hipStream_t st) {
+static int dispatch_block(int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
   switch (B) {
-    case 8: return launch<E, D, 8>(a, plan_ready, st);
-    case 16: return launch<E, D, 16>(a, plan_ready, st);
-    case 32: return launch<E, D, 32>(a, plan_ready, st);
+    case 8: return launch<E, D, 8>(a, tpp, plan_ready, st);
+    case 16: return launch<E, D, 16>(a, tpp, plan_ready, st);
+    case 32: return launch<E, D, 32>(a, tpp, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported block size: %d (supported: 8, 16, 32)", B);
   }
 }
 
 template <typename E>
-static int dispatch_head(int D, int B, const DecodeArgs& a, bool plan_ready, hipStream_t st) {
+static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
   switch (D) {
-    case 64: return dispatch_block<E, 64>(B, a, plan_ready, st);
-    case 80: return dispatch_block<E, 80>(B, a, plan_ready, st);
-    case 96: return dispatch_block<E, 96>(B, a, plan_ready, st);
-    case 128: return dispatch_block<E, 128>(B, a, plan_ready, st);
+    case 64: return dispatch_block<E, 64>(B, a, tpp, plan_ready, st);
+    case 80: return dispatch_block<E, 80>(B, a, tpp, plan_ready, st);
+    case 96: return dispatch_block<E, 96>(B, a, tpp, plan_ready, st);
+    case 128: return dispatch_block<E, 128>(B, a, tpp, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported head size: %d (supported: 64, 80, 96, 128)", D);
   }
 }
@@ -1026,9 +1023,18 @@ static int dispatch_head(int D, int B, const DecodeArgs& a, bool plan_ready, hip
 // against 13 us unsplit, at 128 rows there is no gain, and the gain grows with
 // the context length.  A partition is never shorter than one block per wave,
 // nor than 64 tokens.
-constexpr int kSplitTargetWorkgroups = 1024;   // uniform partitions: aim for this many workgroups
-constexpr int kSplitMaxRows = 256;             // ... for launches of at most this many rows
-constexpr int kSplitMinRowTokens = 0;          // ... whose rows x longest context is at least this
+// Uniform partitions (few rows).  A row streamed by one CU moves about 40 GB/s however many
+// waves work on it (12 waves per row measured the same as 4): the CU's outstanding misses are
+// the limit, so a launch of fewer rows than CUs has to spread each row over several CUs.
+// A target of 768 workgroups — what the chip holds at a time at head size 128 — beats 1024 (a
+// second, mostly empty round) and more.  The partitions are combined by a second launch:
+// letting the last partition of a row to finish combine them in the same launch (write-through
+// partials, an agent-scope ticket per row) measured 1 us SLOWER on 32 rows, the drain, the
+// ticket's round trip and the dependent reads costing more than the launch boundary saved.
+constexpr int kSplitTargetWorkgroups = 768;    // aim for this many workgroups
+constexpr int kSplitAlwaysRows = 64;           // always for launches of at most this many rows
+constexpr int kSplitMaxRows = 256;             // ... and up to this many rows
+constexpr int kSplitMinRowTokens = 256 * 1024; // ... when rows x longest context is at least this
 
 struct PartitionPlan {
   int num_parts;
@@ -1061,14 +1067,26 @@ static void plan_balance(PartitionPlan& p, int num_seqs, int num_heads) {
   p.slots_per_xcd = slots;
 }
 
-// kModeList: partitions of at least this many tokens, at most kListMaxParts of
-// them, for every batch of more than 256 rows whose longest context exceeds one
-// partition.  Measured at a longest context of 2048 tokens (32 heads x 128):
-// batches of random lengths gain 3 % (32 or 64 sequences) to 6 % (256), a batch
-// of 64 with one long sequence 29 %; batches in which every sequence has
-// exactly 2048 tokens lose 3 %.
-constexpr int kListPartTokens = 1024;
-constexpr int kListMaxParts = 4;
+// kModeList: partitions of a fixed length, as many as each sequence needs, for every batch
+// of more than 256 rows whose longest context exceeds one partition.  The fewer rows a launch
+// has against the 768 workgroups the chip holds, the more one long row sets the launch time and
+// the finer the partitions that pay: at most 16 of at least 256 tokens up to 4096 rows, 8 of
+// 512 up to 8192 rows, 4 of 1024 beyond (the partial results take rows x parts x (head size
+// + 2) floats of workspace).  Measured (32 heads x 128, against 4 partitions of 1024 tokens
+// throughout): 64 sequences of 64 tokens and one of 2048: 56.8 -> 32.6 us; 256 sequences of 256
+// and one of 8192: 245 -> 219 us; 32 / 64 sequences of random lengths <= 2048: 96 -> 88 /
+// 177 -> 167 us; batches of equal or long-tailed lengths: unchanged within the box's noise.
+constexpr int kListPartTokens = 256;   // shortest partition
+constexpr int kListMaxParts = 16;      // most partitions per row
+constexpr int kListPartsRowBudget = 65536;  // rows x partitions per row stays within this
+
+static int list_max_parts_for(int64_t rows) {
+  static const int forced = tuning_int("PA_DECODE_LIST_MAX_PARTS", 0);
+  if (forced > 0) return forced;
+  int parts = kListMaxParts;
+  while (parts > 4 && rows * parts > kListPartsRowBudget) parts /= 2;
+  return parts;
+}
 
 static int waves_for(int head_size) { return head_size <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves; }
 
@@ -1083,12 +1101,18 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   static const int target_wgs = tuning_int("PA_DECODE_TARGET_WGS", kSplitTargetWorkgroups);
   static const int split_rows = tuning_int("PA_DECODE_SPLIT_ROWS", kSplitMaxRows);
   static const int split_tokens = tuning_int("PA_DECODE_SPLIT_TOKENS", kSplitMinRowTokens);
-  const bool worth_it = rows <= split_rows && (int64_t)max_context_len * rows >= split_tokens;
+  const bool worth_it = rows <= kSplitAlwaysRows || (rows <= split_rows && (int64_t)max_context_len * rows >= split_tokens);
   int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
   static const int list_mode = tuning_int("PA_DECODE_LIST", -1);  // tuning builds: 0 = never use the item list
-  int list_bpp = std::max(kListPartTokens / block_size, (max_blocks + kListMaxParts - 1) / kListMaxParts);
+  const int list_max_parts = list_max_parts_for(rows);
+  // 16 partitions of 256 tokens, 8 of 512, 4 of 1024: a row of up to 4096 tokens uses them all
+  static const int forced_part_tokens = tuning_int("PA_DECODE_LIST_PART_TOKENS", 0);
+  const int list_part_tokens = forced_part_tokens > 0 ? forced_part_tokens : kListPartTokens * kListMaxParts / list_max_parts;
+  int list_bpp = std::max(list_part_tokens / block_size, (max_blocks + list_max_parts - 1) / list_max_parts);
   list_bpp = (list_bpp + num_waves - 1) / num_waves * num_waves;
-  const bool long_contexts = max_blocks > list_bpp;  // some sequence can have a second partition
+  // some sequence can have a second partition; with thousands of rows (ten and more per resident
+  // workgroup) a row of up to 1024 tokens cannot hold up the launch, whatever the others are
+  const bool long_contexts = max_blocks > list_bpp && (rows <= 4096 || max_context_len > 1024);
   if (want <= 1 && list_mode != 0 && long_contexts && num_seqs < (1 << (32 - kItemPartBits))) {
     const int parts = (max_blocks + list_bpp - 1) / list_bpp;
     if (parts > 1 && rows * parts < (1ll << 31)) {
@@ -1110,12 +1134,11 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
 
 // Workspace: the balanced order's row table [8][slots_per_xcd] of int2 first
 // (if any); with partitions, accumulators [rows * parts][D], then (max, sum)
-// pairs [rows * parts][2], fp32, then the stamp and the rows' ticket words
-// [1 + rows]; kModeList appends the item list [num_seqs * parts] and the three
-// counters.
+// pairs [rows * parts][2], fp32; kModeList appends the item list
+// [num_seqs * parts] and the three counters.
 static size_t workspace_bytes_for(int64_t rows, const PartitionPlan& p, int head_size, int64_t num_seqs) {
   size_t n = p.slots_per_xcd > 0 ? ((size_t)8 * p.slots_per_xcd + 1) * sizeof(int2) : 0;  // + the stamp
-  if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float) + ((size_t)rows + 1) * sizeof(unsigned);
+  if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float);
   if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * p.num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
   return n;
 }
@@ -1156,7 +1179,6 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.items = nullptr;
   a.counters = nullptr;
   a.list_slots = 0;
-  a.merge_cnt = nullptr;
   a.q_stride = q_stride;
   a.scale_log2e = scale * 1.4426950408889634f;
   a.num_seqs = num_seqs;
@@ -1216,21 +1238,28 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
         a.blocks_per_part = p.blocks_per_part;
         a.ws_acc = reinterpret_cast<float*>(base);
         a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
-        a.merge_cnt = reinterpret_cast<unsigned*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
         if (p.list) {
-          uint32_t* tail = a.merge_cnt + (size_t)rows + 1;
+          uint32_t* tail = reinterpret_cast<uint32_t*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
           a.items = tail;
           a.counters = tail + (size_t)num_seqs * p.num_parts;
-          a.list_slots = (unsigned)(rows * (p.num_parts - 1));
+          // One workgroup id per (sequence, partition >= 1, head) that could exist.  A sequence of
+          // n blocks has at most n / blocks_per_part partitions beyond its first, so with the sum
+          // of the context lengths known the batch has at most (total / block_size + num_seqs) /
+          // blocks_per_part of them: far fewer ids to dispatch than num_seqs * (parts - 1).
+          int64_t pairs = (int64_t)num_seqs * (p.num_parts - 1);
+          if (total_context_len >= 0)
+            pairs = std::min<int64_t>(pairs, (total_context_len / block_size + num_seqs) / p.blocks_per_part);
+          a.list_slots = (unsigned)(pairs * num_heads);
         }
       }
     }
   }
+  const int tokens_per_part = a.blocks_per_part * block_size;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, plan_mode == kPlanReady, st);
-    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, plan_mode == kPlanReady, st);
-    default: return dispatch_head<ElemBF16>(head_size, block_size, a, plan_mode == kPlanReady, st);
+    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
+    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
+    default: return dispatch_head<ElemBF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
   }
 }
 
