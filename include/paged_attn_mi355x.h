@@ -296,6 +296,25 @@ int pa_rotary_embedding_neox(
     int64_t query_stride, int64_t key_stride, int dtype, void* stream);
 
 /*
+ * pa_rotary_embedding_neox followed by pa_reshape_and_cache, in one pass where the
+ * shapes allow.  Replaces the pair of calls a rotary attention layer makes for the
+ * tokens it caches (vllm/model_executor/layers/attention.py:200-206 rotary_embedding_neox,
+ * then :134-140 reshape_and_cache; kernels csrc/pos_encoding_kernels.cu:7-47 and
+ * csrc/cache_kernels.cu:143-182).  query and key are rotated in place, the rotated
+ * key and the value are written to the caches; query, key and both caches end up
+ * bit-identical to the two separate calls.  Decode-sized batches (16 to 511 tokens,
+ * 16-byte aligned rows, rot_dim / 2 a multiple of 16 bytes) are one kernel that reads
+ * the key once; everything else is run as the two operators.  A negative slot
+ * rotates the token and caches nothing.
+ */
+int pa_rotary_embedding_neox_reshape_and_cache(
+    const int64_t* positions, void* query, void* key, const void* value,
+    const void* cos_sin_cache, void* key_cache, void* value_cache,
+    const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
+    int rot_dim, int block_size, int64_t query_stride, int64_t key_stride,
+    int64_t value_stride, int dtype, void* stream);
+
+/*
  * out = ((T)(x * rsqrt(mean(x^2) + epsilon))) * weight per row.  Replaces
  * rms_norm (csrc/layernorm_kernels.cu:38-63; kernel :10-34).  out, input:
  * [num_tokens, hidden_size] dense; weight: [hidden_size].

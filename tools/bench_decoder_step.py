@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--two-call-rotary", action="store_true",
+                    help="rotary_embedding_neox then reshape_and_cache as two calls (the reference's sequence) instead "
+                         "of the one-pass operator for the generation tokens")
     args = ap.parse_args()
     pkg = __graft_entry__.load_package()
     from vllm_amd.input_metadata import InputMetadata
@@ -60,7 +63,11 @@ def main():
             kc=torch.empty(NB, H, D // 8, B, 8, dtype=dt, device=dev).normal_(0, 0.5),
             vc=torch.empty(NB, H, D, B, dtype=dt, device=dev).normal_(0, 0.5)))
     final_norm = RMSNorm(hidden).to(dev)
-    attn = PagedAttentionWithRoPE(H, D, D ** -0.5, rotary_dim=D, max_position=2048).to(dev)
+    cache_ops = None
+    if args.two_call_rotary:
+        import types
+        cache_ops = types.SimpleNamespace(reshape_and_cache=pkg.cache_ops.reshape_and_cache)
+    attn = PagedAttentionWithRoPE(H, D, D ** -0.5, rotary_dim=D, max_position=2048, cache_ops=cache_ops).to(dev)
     act = SiluAndMul()
     g = torch.Generator(device="cpu").manual_seed(0)
     block_tables = torch.randperm(NB, generator=g).to(torch.int32).reshape(S, bps).to(dev)
@@ -111,7 +118,8 @@ def main():
     graph_ms = time_it(graph.replay, args.steps)
     wbytes = sum(t.numel() * 2 for ly in layers for t in (ly["qkv"], ly["o"], ly["gate_up"], ly["down"])) + lm_head.numel() * 2
     kvbytes = L * 2 * S * CTX * H * D * 2
-    print(f"LLaMA-{args.model} decode step, batch {S}, ctx {CTX}, {L} layers, fp16, random weights")
+    print(f"LLaMA-{args.model} decode step, batch {S}, ctx {CTX}, {L} layers, fp16, random weights, "
+          f"{'rotary + reshape_and_cache as two calls' if args.two_call_rotary else 'rotary + reshape_and_cache in one pass'}")
     print(f"  eager : {eager_ms:8.2f} ms/step  {S / eager_ms * 1e3:10.0f} tokens/s")
     print(f"  graph : {graph_ms:8.2f} ms/step  {S / graph_ms * 1e3:10.0f} tokens/s")
     print(f"  bytes that must stream per step: weights {wbytes / 1e9:.1f} GB + KV {kvbytes / 1e9:.1f} GB "
@@ -129,6 +137,8 @@ def main():
         t = getattr(ev, "device_time_total", None) or getattr(ev, "cuda_time_total", 0)
         if "pa_decode" in name:
             key = "paged attention (decode)"
+        elif "pa_rotary_append" in name:
+            key = "rotary + reshape_and_cache (one pass)"
         elif "pa_token" in name:
             key = "reshape_and_cache"
         elif "rms_norm" in name or "rotary" in name or "silu" in name:

@@ -34,6 +34,7 @@ EXPORTS = (
     "pa_decode_workspace_bytes",
     "pa_multi_query_kv_attention",
     "pa_reshape_and_cache",
+    "pa_rotary_embedding_neox_reshape_and_cache",
     "pa_gather_cached_kv",
     "pa_copy_blocks",
     "pa_swap_blocks",
@@ -81,6 +82,9 @@ def _load() -> ctypes.CDLL:
     for fn in (lib.pa_reshape_and_cache, lib.pa_gather_cached_kv):
         fn.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp]
         fn.restype = i32
+    lib.pa_rotary_embedding_neox_reshape_and_cache.argtypes = [
+        vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i32, vp]
+    lib.pa_rotary_embedding_neox_reshape_and_cache.restype = i32
     lib.pa_copy_blocks.argtypes = [vp, vp, i32, vp, i32, i64, vp]
     lib.pa_copy_blocks.restype = i32
     lib.pa_swap_blocks.argtypes = [vp, vp, vp, i32, i64, i32, vp]
@@ -202,6 +206,19 @@ def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, stream=N
     rc = lib.pa_reshape_and_cache(
         key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
         slot_mapping.data_ptr(), T, H, D, value_cache.shape[3], key.stride(0) if T > 0 else 0,
+        value.stride(0) if T > 0 else 0, dtype_code(key.dtype), _stream_handle(stream))
+    check(rc)
+
+
+def rotary_embedding_neox_reshape_and_cache(positions, query, key, value, key_cache, value_cache, slot_mapping,
+                                            cos_sin_cache, stream=None) -> None:
+    """query / key / value: [T, H, D] views (row strides free); rotates query and key in place and
+    writes the rotated key and the value into the caches."""
+    T, H, D = key.shape
+    rc = lib.pa_rotary_embedding_neox_reshape_and_cache(
+        positions.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), cos_sin_cache.data_ptr(),
+        key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr(), T, H, D, cos_sin_cache.shape[1],
+        value_cache.shape[3], query.stride(0) if T > 0 else 0, key.stride(0) if T > 0 else 0,
         value.stride(0) if T > 0 else 0, dtype_code(key.dtype), _stream_handle(stream))
     check(rc)
 

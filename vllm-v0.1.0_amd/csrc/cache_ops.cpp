@@ -139,6 +139,36 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value, torch::Tensor& 
                what);
 }
 
+// No counterpart as ONE function in the reference: the pair of calls a rotary attention layer
+// makes for the tokens it caches, pos_encoding_ops.rotary_embedding_neox(positions, query, key,
+// head_size, cos_sin_cache) then cache_ops.reshape_and_cache(key, value, key_cache, value_cache,
+// slot_mapping) (vllm/model_executor/layers/attention.py:200-206, :134-140), with the same
+// results in query, key and the caches.  query / key / value are [num_tokens, num_heads, head_size]
+// views of the fused projection.
+void rotary_embedding_neox_reshape_and_cache(torch::Tensor& positions, torch::Tensor& query, torch::Tensor& key,
+                                             torch::Tensor& value, torch::Tensor& key_cache,
+                                             torch::Tensor& value_cache, torch::Tensor& slot_mapping,
+                                             torch::Tensor& cos_sin_cache) {
+  const char* what = "rotary_embedding_neox_reshape_and_cache";
+  const TokenCacheArgs a = check_token_cache(what, key, value, key_cache, value_cache, slot_mapping);
+  TORCH_CHECK(positions.is_cuda() && query.is_cuda() && cos_sin_cache.is_cuda(), what, ": all tensors must be on the GPU");
+  check_token_rows(query, "query");
+  TORCH_CHECK(query.sizes() == key.sizes() && query.scalar_type() == key.scalar_type() &&
+                  cos_sin_cache.scalar_type() == key.scalar_type(),
+              what, ": query, key and cos_sin_cache must share shape / data type");
+  TORCH_CHECK(positions.scalar_type() == at::ScalarType::Long && positions.is_contiguous() &&
+                  positions.numel() >= a.num_tokens,
+              what, ": positions must be a contiguous int64 tensor with one entry per token");
+  TORCH_CHECK(cos_sin_cache.dim() == 2 && cos_sin_cache.is_contiguous(), what,
+              ": cos_sin_cache must be a contiguous [max_position, rot_dim] tensor");
+  check_status(pa_rotary_embedding_neox_reshape_and_cache(
+                   positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+                   cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int>(),
+                   a.num_tokens, a.num_heads, a.head_size, static_cast<int>(cos_sin_cache.size(1)), a.block_size,
+                   a.num_tokens > 0 ? query.stride(0) : 0, a.key_stride, a.value_stride, a.dtype, current_stream(key)),
+               what);
+}
+
 // csrc/cache_kernels.cu:348-386
 void gather_cached_kv(torch::Tensor& key, torch::Tensor& value, torch::Tensor& key_cache, torch::Tensor& value_cache,
                       torch::Tensor& slot_mapping) {
@@ -157,4 +187,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("copy_blocks", &copy_blocks, "Copy cache blocks src -> dst inside every layer's key and value cache");
   m.def("reshape_and_cache", &reshape_and_cache, "Scatter new key/value vectors into the paged caches");
   m.def("gather_cached_kv", &gather_cached_kv, "Gather key/value vectors from the paged caches into token rows");
+  m.def("rotary_embedding_neox_reshape_and_cache", &rotary_embedding_neox_reshape_and_cache,
+        "rotary_embedding_neox on query and key in place, then reshape_and_cache of key and value: one pass");
 }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "pa_common.h"
+#include "pa_exact_math.h"
 
 namespace pa {
 
@@ -194,6 +195,131 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
   const int per = (total + gridDim.y - 1) / gridDim.y;
   const int lo = per * blockIdx.y, hi = min(lo + per, total);
   constexpr int U = 4;  // vectors in flight per lane
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      if (i < hi) v[u] = __builtin_nontemporal_load(tile + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      if (i >= hi) continue;
+      const int r = i / vpr;
+      if (i - r * vpr == piece) {
+        const elem_t val = reinterpret_cast<const elem_t*>(vrow)[r];
+        if (ES == 4) {
+          v[u][lane_el] = (uint32_t)val;
+        } else {
+          const int w = lane_el >> 1, sh = (lane_el & 1) * 16;
+          v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)val << sh);
+        }
+      }
+      __builtin_nontemporal_store(v[u], tile + i);
+    }
+  }
+}
+
+// ---- rotary embedding + reshape_and_cache in one pass (decode-sized batches) ---------
+//
+// In a decoder layer with rotary position embedding the new token's key is rotated in place
+// and then copied into the key cache: two kernels, the second re-reading what the first just
+// wrote (vllm/model_executor/layers/attention.py:200-206, then :134-140).  Here the workgroups of
+// a token rotate its query row in place and its key row in place AND into the cache, from one
+// read; the values go the way of pa_token_append_kernel.  Same arithmetic as
+// pa_rotary_neox_kernel (every product and sum rounded to T), so query, key and both caches end
+// up bit-identical to the two separate calls.  A token without a slot (negative) is rotated and
+// not cached, as the two calls would do.
+//
+// Per head the D / X vectors of a row are: embed / X "x" vectors, their embed / X partners
+// ("y", rot_dim / 2 elements further on), and (D - rot_dim) / X vectors the rotation leaves
+// alone.  One work item = an (x, y) pair, or one untouched vector.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ query, T* __restrict__ key,
+                        const T* __restrict__ value, const T* __restrict__ cos_sin_cache, char* __restrict__ key_cache,
+                        char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_tokens,
+                        const int num_heads, const int head_size, const int rot_dim, const int block_size,
+                        const int64_t query_stride, const int64_t key_stride, const int64_t value_stride) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int X = 16 / ES;
+  typedef Pack<T, X> P;
+  typedef typename Word<ES>::type elem_t;
+  const int token = blockIdx.x;
+  const int slot = slot_mapping[token];
+  const int64_t blk = slot >= 0 ? slot / block_size : 0;
+  const int off = slot >= 0 ? slot % block_size : 0;
+  int clash = 0;
+  if (slot >= 0) {
+    for (int t = threadIdx.x; t < num_tokens; t += blockDim.x) {
+      const int s = slot_mapping[t];
+      clash |= (t != token && s >= 0 && s / block_size == blk) ? 1 : 0;
+    }
+  }
+  clash = __syncthreads_or(clash);
+
+  const int n = num_heads * head_size;
+  T* qrow = query + (int64_t)token * query_stride;
+  T* krow = key + (int64_t)token * key_stride;
+  const T* vrow = value + (int64_t)token * value_stride;
+  const T* cs = cos_sin_cache + positions[token] * rot_dim;
+  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
+  const int embed = rot_dim / 2;
+  const int ndx = head_size / X;   // vectors per head
+  const int epx = embed / X;       // (x, y) pairs per head
+  const int per_head = ndx - epx;  // work items per head
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < num_heads * per_head; i += gridDim.y * blockDim.x) {
+    const int h = i / per_head;
+    const int j = i - h * per_head;
+    T* kb = krow + (int64_t)h * head_size;
+    // key cache [blk][h][dx][off][x]: vector dx of head h
+    auto kc_vec = [&](int dx) {
+      return reinterpret_cast<u32x4*>(key_cache + (cache_block + (((int64_t)h * ndx + dx) * block_size + off) * X) * ES);
+    };
+    if (j < epx) {
+      const int xo = j * X;
+      const P c = *reinterpret_cast<const P*>(cs + xo);
+      const P sn = *reinterpret_cast<const P*>(cs + embed + xo);
+      T* qb = qrow + (int64_t)h * head_size;
+      const P qx = *reinterpret_cast<const P*>(qb + xo), qy = *reinterpret_cast<const P*>(qb + embed + xo);
+      const P kx = *reinterpret_cast<const P*>(kb + xo), ky = *reinterpret_cast<const P*>(kb + embed + xo);
+      P oqx, oqy, okx, oky;
+#pragma unroll
+      for (int e = 0; e < X; e++) {
+        oqx.v[e] = sub_t(mul_t(qx.v[e], c.v[e]), mul_t(qy.v[e], sn.v[e]));
+        oqy.v[e] = add_t(mul_t(qy.v[e], c.v[e]), mul_t(qx.v[e], sn.v[e]));
+        okx.v[e] = sub_t(mul_t(kx.v[e], c.v[e]), mul_t(ky.v[e], sn.v[e]));
+        oky.v[e] = add_t(mul_t(ky.v[e], c.v[e]), mul_t(kx.v[e], sn.v[e]));
+      }
+      *reinterpret_cast<P*>(qb + xo) = oqx;
+      *reinterpret_cast<P*>(qb + embed + xo) = oqy;
+      *reinterpret_cast<P*>(kb + xo) = okx;
+      *reinterpret_cast<P*>(kb + embed + xo) = oky;
+      if (slot >= 0) {
+        store_cache(kc_vec(j), __builtin_bit_cast(u32x4, okx));
+        store_cache(kc_vec(j + epx), __builtin_bit_cast(u32x4, oky));
+      }
+    } else if (slot >= 0) {
+      const int dx = j + epx;  // beyond the rotated part
+      store_cache(kc_vec(dx), *reinterpret_cast<const u32x4*>(kb + dx * X));
+    }
+  }
+  if (slot < 0) return;
+  if (clash) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x)
+      reinterpret_cast<elem_t*>(value_cache)[cache_block + (int64_t)i * block_size + off] =
+          reinterpret_cast<const elem_t*>(vrow)[i];
+    return;
+  }
+  // values: read the block's tile, put the new elements in, write it back (see pa_token_append_kernel)
+  const int vpr = block_size / X;
+  const int piece = off / X, lane_el = off % X;
+  u32x4* tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
+  const int total = n * vpr;
+  const int per = (total + gridDim.y - 1) / gridDim.y;
+  const int lo = per * blockIdx.y, hi = min(lo + per, total);
+  constexpr int U = 4;
   for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
     u32x4 v[U];
 #pragma unroll
@@ -444,6 +570,25 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
   return PA_OK;
 }
 
+template <typename T>
+static void launch_rotary_append(const int64_t* positions, void* query, void* key, const void* value,
+                                 const void* cos_sin_cache, void* key_cache, void* value_cache,
+                                 const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size, int rot_dim,
+                                 int block_size, int64_t query_stride, int64_t key_stride, int64_t value_stride,
+                                 hipStream_t st) {
+  constexpr int X = 16 / (int)sizeof(T);
+  const int tile_vecs = num_heads * head_size * (block_size / X);
+  int sl = (2048 + num_tokens - 1) / num_tokens;  // ~8 workgroups per CU, as for pa_token_append_kernel
+  const int most = (tile_vecs + 4 * 256 - 1) / (4 * 256);
+  if (sl > most) sl = most;
+  if (sl < 1) sl = 1;
+  hipLaunchKernelGGL((pa_rotary_append_kernel<T>), dim3(num_tokens, sl), dim3(256), 0, st, positions,
+                     static_cast<T*>(query), static_cast<T*>(key), static_cast<const T*>(value),
+                     static_cast<const T*>(cos_sin_cache), static_cast<char*>(key_cache), static_cast<char*>(value_cache),
+                     slot_mapping, num_tokens, num_heads, head_size, rot_dim, block_size, query_stride, key_stride,
+                     value_stride);
+}
+
 // ---- copy_blocks ---------------------------------------------------------------
 //
 // The layer pointer table and the (src, dst) pairs ride in the kernel
@@ -542,6 +687,53 @@ extern "C" int pa_reshape_and_cache(const void* key, const void* value, void* ke
   return pa::token_cache_op<false>("pa_reshape_and_cache", const_cast<void*>(key), const_cast<void*>(value),
                                    key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
                                    block_size, key_stride, value_stride, dtype, stream);
+}
+
+extern "C" int pa_rotary_embedding_neox_reshape_and_cache(
+    const int64_t* positions, void* query, void* key, const void* value, const void* cos_sin_cache, void* key_cache,
+    void* value_cache, const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size, int rot_dim,
+    int block_size, int64_t query_stride, int64_t key_stride, int64_t value_stride, int dtype, void* stream) {
+  using namespace pa;
+  clear_error();
+  const char* what = "pa_rotary_embedding_neox_reshape_and_cache";
+  if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
+    return fail(PA_ERR_UNSUPPORTED, "%s: unsupported data type code: %d", what, dtype);
+  PA_REQUIRE(num_tokens >= 0 && num_heads >= 0 && head_size >= 0 && rot_dim >= 0 && block_size > 0,
+             "%s: negative size or non-positive block size", what);
+  PA_REQUIRE(rot_dim % 2 == 0 && rot_dim <= head_size, "%s: rot_dim %d must be even and <= head_size %d", what,
+             rot_dim, head_size);
+  if (num_tokens == 0 || num_heads == 0 || head_size == 0) return PA_OK;
+  PA_REQUIRE(positions && query && key && value && cos_sin_cache && key_cache && value_cache && slot_mapping,
+             "%s: null pointer argument", what);
+  const int es = elem_size(dtype);
+  const int x = 16 / es;
+  const bool rows16 = aligned16(query) && aligned16(key) && aligned16(value) && (query_stride * es) % 16 == 0 &&
+                      (key_stride * es) % 16 == 0 && (value_stride * es) % 16 == 0 && (head_size * es) % 16 == 0;
+  const bool fused = rows16 && rot_dim > 0 && (rot_dim / 2) % x == 0 && aligned16(cos_sin_cache) &&
+                     aligned16(key_cache) && aligned16(value_cache) && (block_size * es) % 16 == 0 &&
+                     num_tokens >= kAppendMinTokens && num_tokens < PA_CACHE_RUNS_MIN_TOKENS &&
+                     (int64_t)num_heads * head_size < (1ll << 31);
+  if (!fused) {
+    // Shapes the one-pass kernel does not take (a handful of tokens, prompt-sized batches, odd
+    // alignments) run as the two operators they stand for: same results.
+    int rc = pa_rotary_embedding_neox(positions, query, key, cos_sin_cache, num_tokens, num_heads, head_size, rot_dim,
+                                      query_stride, key_stride, dtype, stream);
+    if (rc != PA_OK) return rc;
+    return pa_reshape_and_cache(key, value, key_cache, value_cache, slot_mapping, num_tokens, num_heads, head_size,
+                                block_size, key_stride, value_stride, dtype, stream);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define PA_ROTARY_APPEND(T)                                                                                            \
+  launch_rotary_append<T>(positions, query, key, value, cos_sin_cache, key_cache, value_cache, slot_mapping, num_tokens, \
+                          num_heads, head_size, rot_dim, block_size, query_stride, key_stride, value_stride, st)
+  switch (dtype) {
+    case PA_DTYPE_F32: PA_ROTARY_APPEND(float); break;
+    case PA_DTYPE_F16: PA_ROTARY_APPEND(_Float16); break;
+    default: PA_ROTARY_APPEND(__bf16); break;
+  }
+#undef PA_ROTARY_APPEND
+  PA_CHECK_LAUNCH(what);
+  return PA_OK;
 }
 
 extern "C" int pa_gather_cached_kv(void* key, void* value, const void* key_cache, const void* value_cache,

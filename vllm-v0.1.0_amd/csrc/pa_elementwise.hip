@@ -12,32 +12,9 @@
 // values whose every operator rounds to the storage type.  This file is
 // therefore built WITHOUT fast-math and with floating-point contraction off.
 #include "pa_common.h"
+#include "pa_exact_math.h"
 
 namespace pa {
-
-template <typename T> struct Num;
-template <> struct Num<float> {
-  static __device__ __forceinline__ float to(float x) { return x; }
-  static __device__ __forceinline__ float from(float x) { return x; }
-};
-template <> struct Num<_Float16> {
-  static __device__ __forceinline__ float to(_Float16 x) { return (float)x; }
-  static __device__ __forceinline__ _Float16 from(float x) { return (_Float16)x; }
-};
-template <> struct Num<__bf16> {
-  static __device__ __forceinline__ float to(__bf16 x) { return (float)x; }
-  static __device__ __forceinline__ __bf16 from(float x) { return (__bf16)x; }
-};
-
-// a op b with the result rounded to T, as c10::Half / c10::BFloat16 operators do
-template <typename T> __device__ __forceinline__ T mul_t(T a, T b) { return Num<T>::from(Num<T>::to(a) * Num<T>::to(b)); }
-template <typename T> __device__ __forceinline__ T add_t(T a, T b) { return Num<T>::from(Num<T>::to(a) + Num<T>::to(b)); }
-template <typename T> __device__ __forceinline__ T sub_t(T a, T b) { return Num<T>::from(Num<T>::to(a) - Num<T>::to(b)); }
-
-template <typename T, int N>
-struct alignas(16) Pack {
-  T v[N];
-};
 
 // ---- rotary_embedding_neox ------------------------------------------------------
 //

@@ -98,7 +98,10 @@ class PagedAttention(nn.Module):
         value_cache: Optional[torch.Tensor],
         input_metadata: InputMetadata,
         cache_event: Optional[torch.cuda.Event],
+        _generation_tokens_cached: bool = False,
     ) -> torch.Tensor:                        # [num_tokens, num_heads * head_size]
+        # _generation_tokens_cached: the caller (PagedAttentionWithRoPE) has already written the
+        # generation tokens' key and value into the caches.
         # query/key/value are column slices of the fused qkv projection: the
         # views below keep their row stride.
         query = query.view(-1, self.num_heads, self.head_size)
@@ -124,7 +127,10 @@ class PagedAttention(nn.Module):
             # One call per kind of token (the reference makes one call for all, :131-140):
             # prompts fill runs of consecutive slots, generation tokens one slot in a block
             # of their own, and the operator picks its kernel by what a call contains.
-            for lo, hi in ((0, num_prompt_tokens), (num_prompt_tokens, num_valid_tokens)):
+            spans = [(0, num_prompt_tokens)]
+            if not _generation_tokens_cached:
+                spans.append((num_prompt_tokens, num_valid_tokens))
+            for lo, hi in spans:
                 if hi > lo:
                     self._cache_ops.reshape_and_cache(
                         key[lo:hi],
@@ -179,5 +185,24 @@ class PagedAttentionWithRoPE(PagedAttention):
         cache_event: Optional[torch.cuda.Event],
     ) -> torch.Tensor:
         # in place on the q and k column slices of the fused qkv row
-        self._pos_encoding_ops.rotary_embedding_neox(positions, query, key, self.head_size, self.cos_sin_cache)
-        return super().forward(query, key, value, key_cache, value_cache, input_metadata, cache_event)
+        fused = getattr(self._cache_ops, "rotary_embedding_neox_reshape_and_cache", None)
+        n_prompt, n_valid = input_metadata.num_prompt_tokens, input_metadata.num_valid_tokens
+        if fused is None or key_cache is None or value_cache is None or n_valid <= n_prompt:
+            self._pos_encoding_ops.rotary_embedding_neox(positions, query, key, self.head_size, self.cos_sin_cache)
+            return super().forward(query, key, value, key_cache, value_cache, input_metadata, cache_event)
+        # Generation tokens: rotation and cache write in one pass over the key (the rotated key of
+        # a generation token has no other reader; prompt tokens' keys are also read by the prompt
+        # attention, so they are rotated first and cached by the base class as before).  Padding
+        # rows behind the valid tokens are left alone: nothing reads them.
+        if n_prompt > 0:
+            self._pos_encoding_ops.rotary_embedding_neox(positions[:n_prompt], query[:n_prompt], key[:n_prompt],
+                                                         self.head_size, self.cos_sin_cache)
+        if cache_event is not None:
+            cache_event.wait()  # the swap of this layer's blocks must have landed before the cache is written
+            cache_event = None
+        H, D = self.num_heads, self.head_size
+        fused(positions[n_prompt:n_valid], query[n_prompt:n_valid].view(-1, H, D), key[n_prompt:n_valid].view(-1, H, D),
+              value[n_prompt:n_valid].view(-1, H, D), key_cache, value_cache,
+              input_metadata.slot_mapping[n_prompt:n_valid], self.cos_sin_cache)
+        return super().forward(query, key, value, key_cache, value_cache, input_metadata, cache_event,
+                               _generation_tokens_cached=True)
