@@ -17,6 +17,7 @@ void silu_and_mul(torch::Tensor& out,    // [num_tokens, d]
               ": out and input must be contiguous 2-d tensors");
   TORCH_CHECK(input.size(1) % 2 == 0 && out.size(0) == input.size(0) && out.size(1) * 2 == input.size(1), what,
               ": input must be [num_tokens, 2 * d] and out [num_tokens, d]");
+  PA_DEVICE_GUARD(input);
   check_status(pa_silu_and_mul(out.data_ptr(), input.data_ptr(), static_cast<int>(input.size(0)),
                                static_cast<int>(out.size(1)), dtype, current_stream(input)),
                what);

@@ -60,6 +60,7 @@ void single_query_cached_kv_attention(
   if (ws_bytes > 0) {
     workspace = torch::empty({static_cast<int64_t>(ws_bytes)}, query.options().dtype(torch::kUInt8));
   }
+  PA_DEVICE_GUARD(query);
   check_status(pa_single_query_cached_kv_attention_ws(
                    out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
                    block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs, sh.num_heads, sh.head_size,
@@ -90,6 +91,7 @@ void single_query_cached_kv_attention_planned(
                                          workspace.scalar_type() == at::ScalarType::Byte),
               what, ": workspace must be a contiguous uint8 tensor on the GPU");
   const size_t ws_bytes = static_cast<size_t>(workspace.numel());
+  PA_DEVICE_GUARD(query);
   check_status(pa_single_query_cached_kv_attention_planned(
                    out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), scale,
                    block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs, sh.num_heads, sh.head_size,
@@ -128,6 +130,7 @@ void multi_query_kv_attention(
   }
   const int64_t row = query.size(1) * query.size(2);
   const bool any = query.size(0) > 0;
+  PA_DEVICE_GUARD(query);
   check_status(pa_multi_query_kv_attention(out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), cu.data(),
                                            static_cast<int>(seq_lens.size()), static_cast<int>(query.size(1)),
                                            static_cast<int>(query.size(2)), scale, any ? query.stride(0) : row,

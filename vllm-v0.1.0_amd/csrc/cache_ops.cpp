@@ -46,6 +46,7 @@ void swap_blocks(torch::Tensor& src, torch::Tensor& dst, const std::map<int64_t,
     pairs.push_back(kv.first);
     pairs.push_back(kv.second);
   }
+  PA_DEVICE_GUARD(*gpu_side);
   check_status(pa_swap_blocks(src.data_ptr(), dst.data_ptr(), pairs.data(), static_cast<int>(block_mapping.size()),
                               block_bytes, kind, current_stream(*gpu_side)),
                what);
@@ -86,6 +87,7 @@ void copy_blocks(std::vector<torch::Tensor>& key_caches, std::vector<torch::Tens
     }
   }
   if (pairs.empty()) return;
+  PA_DEVICE_GUARD(key_caches[0]);
   check_status(pa_copy_blocks(kptrs.data(), vptrs.data(), num_layers, pairs.data(), static_cast<int>(pairs.size() / 2),
                               block_bytes, current_stream(key_caches[0])),
                what);
@@ -133,6 +135,7 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value, torch::Tensor& 
                        torch::Tensor& slot_mapping) {
   const char* what = "reshape_and_cache";
   const TokenCacheArgs a = check_token_cache(what, key, value, key_cache, value_cache, slot_mapping);
+  PA_DEVICE_GUARD(key);
   check_status(pa_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
                                     slot_mapping.data_ptr<int>(), a.num_tokens, a.num_heads, a.head_size, a.block_size,
                                     a.key_stride, a.value_stride, a.dtype, current_stream(key)),
@@ -161,6 +164,7 @@ void rotary_embedding_neox_reshape_and_cache(torch::Tensor& positions, torch::Te
               what, ": positions must be a contiguous int64 tensor with one entry per token");
   TORCH_CHECK(cos_sin_cache.dim() == 2 && cos_sin_cache.is_contiguous(), what,
               ": cos_sin_cache must be a contiguous [max_position, rot_dim] tensor");
+  PA_DEVICE_GUARD(key);
   check_status(pa_rotary_embedding_neox_reshape_and_cache(
                    positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
                    cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), slot_mapping.data_ptr<int>(),
@@ -174,6 +178,7 @@ void gather_cached_kv(torch::Tensor& key, torch::Tensor& value, torch::Tensor& k
                       torch::Tensor& slot_mapping) {
   const char* what = "gather_cached_kv";
   const TokenCacheArgs a = check_token_cache(what, key, value, key_cache, value_cache, slot_mapping);
+  PA_DEVICE_GUARD(key);
   check_status(pa_gather_cached_kv(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
                                    slot_mapping.data_ptr<int>(), a.num_tokens, a.num_heads, a.head_size, a.block_size,
                                    a.key_stride, a.value_stride, a.dtype, current_stream(key)),

@@ -18,6 +18,7 @@ void rms_norm(torch::Tensor& out,     // [num_tokens, hidden_size]
   TORCH_CHECK(input.dim() == 2 && input.is_contiguous() && out.is_contiguous() && out.sizes() == input.sizes(), what,
               ": out and input must be contiguous [num_tokens, hidden_size] tensors of one shape");
   TORCH_CHECK(weight.is_contiguous() && weight.numel() == input.size(1), what, ": weight must be [hidden_size]");
+  PA_DEVICE_GUARD(input);
   check_status(pa_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), epsilon,
                            static_cast<int>(input.size(0)), static_cast<int>(input.size(1)), dtype,
                            current_stream(input)),

@@ -31,6 +31,7 @@ void rotary_embedding_neox(torch::Tensor& positions,      // [num_tokens]
   TORCH_CHECK(positions.numel() >= num_tokens, what, ": positions is shorter than the number of tokens");
   // the reference requires equal row strides (pos_encoding_kernels.cu:62)
   TORCH_CHECK(num_tokens == 0 || query.stride(0) == key.stride(0), what, ": query and key row strides differ");
+  PA_DEVICE_GUARD(query);
   check_status(pa_rotary_embedding_neox(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(),
                                         cos_sin_cache.data_ptr(), num_tokens,
                                         static_cast<int>(query.size(1) / head_size), head_size,

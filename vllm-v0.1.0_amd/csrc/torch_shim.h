@@ -5,6 +5,7 @@
 // paged_attn_mi355x.h.
 #pragma once
 
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -18,6 +19,12 @@ namespace pa_shim {
 inline void* current_stream(const torch::Tensor& t) {
   return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
 }
+
+// Makes the tensor's device the current one for the duration of a call: the library's
+// per-device set-up (kernel attributes, its own scratch) and its launches go by the current
+// device, while the stream is looked up from the tensor's device.  The reference's launchers
+// have no such guard and misbehave when a tensor lives on a GPU that is not current.
+#define PA_DEVICE_GUARD(tensor) const c10::DeviceGuard pa_device_guard_((tensor).device())
 
 inline int dtype_code(const torch::Tensor& t, const char* what) {
   switch (t.scalar_type()) {
