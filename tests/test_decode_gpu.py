@@ -388,24 +388,45 @@ def test_decode_randomized_shapes_against_oracle(pkg, seed):
         helpers.assert_close(got, ref, atol, 2 * rtol, f"seed {seed} S={S} H={H} D={D} B={B} {dtype} split={split}")
 
 
+def _list_layout_bytes(S, H, D, B, max_ctx, parts_cap, part_tokens, need):
+    """Bytes of the item-list workspace layout with at most parts_cap partitions of at least
+    part_tokens tokens, given `need` = the bytes of the layout with 16 x 256 (what
+    pa_decode_workspace_bytes reports when that is the larger one): the two differ in the
+    partial results (rows x parts x (D + 2) floats) and the item list (S x parts words)."""
+    nw = 8 if D <= 64 else 4
+    mb = (max_ctx + B - 1) // B
+
+    def parts(cap, tokens):
+        bpp = max(tokens // B, (mb + cap - 1) // cap)
+        bpp = (bpp + nw - 1) // nw * nw
+        return (mb + bpp - 1) // bpp
+
+    fine, coarse = parts(16, 256), parts(parts_cap, part_tokens)
+    return need - (fine - coarse) * (S * H * (D + 2) * 4 + S * 4)
+
+
 def test_decode_item_list_plan_splits_only_rows_that_would_hold_up_the_launch(pkg):
     """Item-list mode decides on the device whether partitions pay: they do
     when the longest sequence exceeds half the average work per resident
-    workgroup slot (blocks x heads / slots; 512 slots for head size 64).  A
-    batch of 160 equal-length sequences keeps one workgroup per row (no listed
-    pairs, partition length 'infinite'); the same workspace then serves a
-    mixed batch, which is split, and a batch of 40 equal-length sequences, too
-    few rows to fill the slots, which is split as well.  The plan sits in the
-    last three words of the workspace.  All results must match the oracle."""
+    workgroup slot (blocks x heads / slots; 512 slots for head size 64) —
+    unless all rows are resident at once and the longest is within a quarter of
+    the mean length, when nothing needs evening out.  A batch of 160
+    equal-length sequences keeps one workgroup per row (no listed pairs,
+    partition length 'infinite'); the same workspace then serves a mixed batch,
+    which is split, a batch of 40 equal-length sequences (320 rows, all
+    resident: not split) and 40 sequences with one long one among them (split).
+    The plan sits in the last three words of the workspace.  All results must
+    match the oracle."""
     import torch
     H, D, B = 8, 64, 16
     uniform = [1400 + (13 * i) % 120 for i in range(160)]
     mixed = [3000 if i % 17 == 0 else 150 + i for i in range(160)]
     few = uniform[:40]
-    nbytes = max(pkg._capi.decode_workspace_bytes(len(c), H, D, B, max(c)) for c in (uniform, mixed, few))
+    few_mixed = [2900 if i == 7 else c for i, c in enumerate(few)]
+    nbytes = max(pkg._capi.decode_workspace_bytes(len(c), H, D, B, max(c)) for c in (uniform, mixed, few, few_mixed))
     ws = torch.zeros(nbytes // 4 + 2, dtype=torch.float32, device="cuda:0")
-    for name, ctx, split_expected in (("uniform", uniform, False), ("mixed", mixed, True), ("few rows", few, True),
-                                      ("uniform again", uniform, False)):
+    for name, ctx, split_expected in (("uniform", uniform, False), ("mixed", mixed, True), ("few rows", few, False),
+                                      ("few rows, one long", few_mixed, True), ("uniform again", uniform, False)):
         case = datagen.DecodeCase(name="plan", dtype="float16", num_seqs=len(ctx), num_heads=H, head_size=D, block_size=B,
                                   num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
                                   tables="permutation", seed=91)
@@ -418,12 +439,14 @@ def test_decode_item_list_plan_splits_only_rows_that_would_hold_up_the_launch(pk
         pkg._capi.single_query_cached_kv_attention_ws(out, query, kc, vc, inp["scale"], bt, cl, B,
                                                       inp["max_context_len"], view)
         torch.cuda.synchronize()
-        plan = view.view(torch.int32)[-3:].tolist()
+        # a call without the sum of the context lengths plans at most 4 partitions of >= 1024 tokens
+        used = _list_layout_bytes(len(ctx), H, D, B, inp["max_context_len"], 4, 1024, need)
+        plan = view.view(torch.int32)[used // 4 - 3:used // 4].tolist()
         if split_expected:
             bpp = plan[2]
-            assert bpp * B >= 256 and bpp < (1 << 24), name
+            assert bpp * B >= 1024 and bpp < (1 << 24), name
             most = ((max(ctx) + B - 1) // B + bpp - 1) // bpp  # partitions of the longest context the plan allows for
-            assert 2 <= most <= 16, name
+            assert 2 <= most <= 4, name
             assert plan[1] == sum(min((c + bpp * B - 1) // (bpp * B), most) - 1 for c in ctx), name
             assert plan[1] > 0, name
         else:
@@ -501,9 +524,12 @@ def test_decode_total_context_hint_leaves_the_item_list_out(pkg):
                                                                ready, total)
             torch.cuda.synchronize()
             helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"total={total} ready={ready}")
-        assert bool(torch.isnan(ws[-3:]).all()) != counters_written
+        # without the sum the plan is the 4 x 1024-token one, whose layout ends before the workspace does
+        end = _list_layout_bytes(S, H, D, B, max(ctx), 4, 1024, nbytes) // 4
+        assert bool(torch.isnan(ws[-3:]).all())
+        assert bool(torch.isnan(ws[end - 3:end]).all()) != counters_written
         if counters_written:
-            assert ws.view(torch.int32)[-3:].tolist()[1:] == [0, 1 << 24]
+            assert ws.view(torch.int32)[end - 3:end].tolist()[1:] == [0, 1 << 24]
 
 
 def test_decode_step_replays_from_a_hip_graph(pkg):

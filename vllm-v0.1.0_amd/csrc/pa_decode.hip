@@ -660,7 +660,8 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 
 // Plans one launch from context_lens: one workgroup of kPlanThreads.
 //
-// 1. (item-list form) Whether to split at all.  Partitions exist to keep one
+// 1. (item-list form) Whether to split at all (also not when all rows are resident at once and
+//    the longest is within a quarter of the mean length: nothing to even out).  Partitions exist to keep one
 //    long sequence from setting the launch time alone.  A row workgroup shares
 //    the GPU with resident_slots - 1 others, so the longest row, which starts
 //    first, ends in time as long as it is no longer than the average work per
@@ -745,8 +746,11 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
       }
       __syncthreads();
     }
-    const bool fits = (unsigned long long)scan[0] * 100ull * (unsigned)p.resident_slots <=
-                      sums[0] * (unsigned long long)p.num_heads * (unsigned long long)p.split_pct;
+    bool fits = (unsigned long long)scan[0] * 100ull * (unsigned)p.resident_slots <=
+                sums[0] * (unsigned long long)p.num_heads * (unsigned long long)p.split_pct;
+    // every row resident at once and the longest within a quarter of the mean: the rows end together anyway
+    fits = fits || ((unsigned long long)num_seqs * (unsigned)p.num_heads <= (unsigned)p.resident_slots &&
+                    (unsigned long long)scan[0] * (unsigned)num_seqs * 100ull <= sums[0] * 125ull);
     bpp = fits ? kNoSplitBlocks : p.blocks_per_part;
     __syncthreads();
     for (int s0 = 0; s0 < num_seqs; s0 += nthreads) {
@@ -1080,9 +1084,10 @@ constexpr int kListPartTokens = 256;   // shortest partition
 constexpr int kListMaxParts = 16;      // most partitions per row
 constexpr int kListPartsRowBudget = 65536;  // rows x partitions per row stays within this
 
-static int list_max_parts_for(int64_t rows) {
+static int list_max_parts_for(int64_t rows, bool fine) {
   static const int forced = tuning_int("PA_DECODE_LIST_MAX_PARTS", 0);
   if (forced > 0) return forced;
+  if (!fine) return 4;
   int parts = kListMaxParts;
   while (parts > 4 && rows * parts > kListPartsRowBudget) parts /= 2;
   return parts;
@@ -1090,7 +1095,12 @@ static int list_max_parts_for(int64_t rows) {
 
 static int waves_for(int head_size) { return head_size <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves; }
 
-static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size, int block_size, int max_context_len) {
+// fine: the caller knows the sum of the context lengths, so the launch can reserve workgroup ids
+// for the partitions that sum allows and can tell on the host when none are needed; without it
+// finer partitions would cost every equal-length batch thousands of empty ids and the merge
+// launch (12 heads x 64, 256 x 1024 tokens: 125 -> 143 us), so the list stays at 4 x 1024 tokens.
+static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size, int block_size, int max_context_len,
+                                     bool fine) {
   const int num_waves = waves_for(head_size);
   const int64_t rows = (int64_t)num_seqs * num_heads;
   const int max_blocks = (max_context_len + block_size - 1) / block_size;
@@ -1104,7 +1114,7 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   const bool worth_it = rows <= kSplitAlwaysRows || (rows <= split_rows && (int64_t)max_context_len * rows >= split_tokens);
   int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
   static const int list_mode = tuning_int("PA_DECODE_LIST", -1);  // tuning builds: 0 = never use the item list
-  const int list_max_parts = list_max_parts_for(rows);
+  const int list_max_parts = list_max_parts_for(rows, fine);
   // 16 partitions of 256 tokens, 8 of 512, 4 of 1024: a row of up to 4096 tokens uses them all
   static const int forced_part_tokens = tuning_int("PA_DECODE_LIST_PART_TOKENS", 0);
   const int list_part_tokens = forced_part_tokens > 0 ? forced_part_tokens : kListPartTokens * kListMaxParts / list_max_parts;
@@ -1140,6 +1150,16 @@ static size_t workspace_bytes_for(int64_t rows, const PartitionPlan& p, int head
   size_t n = p.slots_per_xcd > 0 ? ((size_t)8 * p.slots_per_xcd + 1) * sizeof(int2) : 0;  // + the stamp
   if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float);
   if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * p.num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
+  return n;
+}
+
+// enough for either plan: with and without the caller's total context length
+static size_t workspace_bytes_any(int num_seqs, int num_heads, int head_size, int block_size, int max_context_len) {
+  size_t n = 0;
+  for (bool fine : {false, true}) {
+    const PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len, fine);
+    n = std::max(n, workspace_bytes_for((int64_t)num_seqs * num_heads, p, head_size, num_seqs));
+  }
   return n;
 }
 
@@ -1196,7 +1216,8 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.plan_tag = 0;
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
-    PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
+    PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len,
+                                      total_context_len >= 0);
     if (p.list && total_context_len >= 0) {
       // The plan kernel's rule, applied here with what the caller knows: no sequence is
       // longer than max_context_len, and the batch holds at least total / block_size blocks.
@@ -1204,7 +1225,8 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
       // slots and the merge launch are left out altogether.
       const int64_t longest = (max_context_len + block_size - 1) / block_size;
       const int64_t blocks = total_context_len / block_size;
-      if (longest * 100 * resident_slots(head_size) <= blocks * num_heads * split_pct()) {
+      const bool no_straggler = rows <= resident_slots(head_size) && longest * num_seqs * 100 <= blocks * 125;
+      if (no_straggler || longest * 100 * resident_slots(head_size) <= blocks * num_heads * split_pct()) {
         p.num_parts = 1;
         p.list = false;
         p.blocks_per_part = longest > 0 ? (int)longest : 1;
@@ -1303,8 +1325,7 @@ extern "C" int pa_single_query_cached_kv_attention_static(
   size_t need = 0;
   if (num_seqs > 0 && num_heads > 0 && max_context_len > 0 && (head_size == 64 || head_size == 80 || head_size == 96 || head_size == 128) &&
       (block_size == 8 || block_size == 16 || block_size == 32)) {
-    const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
-    need = pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p, head_size, num_seqs);
+    need = pa::workspace_bytes_any(num_seqs, num_heads, head_size, block_size, max_context_len);
   }
   if (need > pa::kStaticScratchBytes)
     return pa::fail(PA_ERR_INVALID_ARGUMENT,
@@ -1334,8 +1355,7 @@ extern "C" int pa_single_query_cached_kv_attention(
 extern "C" size_t pa_decode_workspace_bytes(int num_seqs, int num_heads, int head_size, int block_size,
                                             int max_context_len) {
   if (num_seqs <= 0 || num_heads <= 0 || head_size <= 0 || block_size <= 0 || max_context_len <= 0) return 0;
-  const pa::PartitionPlan p = pa::plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len);
-  return pa::workspace_bytes_for((int64_t)num_seqs * num_heads, p, head_size, num_seqs);
+  return pa::workspace_bytes_any(num_seqs, num_heads, head_size, block_size, max_context_len);
 }
 
 extern "C" int pa_single_query_cached_kv_attention_ws(
