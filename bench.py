@@ -124,9 +124,17 @@ def parse_args(argv=None):
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-c2", action="store_true", help="skip the secondary microbench-shape measurement")
     p.add_argument("--no-tp-leg", action="store_true", help="N > 1 without --tp: skip the extra head-sharded measurement")
+    p.add_argument("--tp-graph", action="store_true",
+                   help="tensor-parallel legs: replay the all-reduce from a HIP graph captured on the side stream "
+                        "(default: direct RCCL calls on the side stream; the graph path has only been exercised with a "
+                        "stand-in collective on one GPU)")
     p.add_argument("--roofline-only", action="store_true",
                    help="launch nothing but isolated decode kernels (5 warm-ups + 40 timed): the command to put "
                         "under rocprofv3 --kernel-trace so that its per-dispatch median reproduces roofline.frac")
+    p.add_argument("--progress", action="store_true", help="print a line per phase and rank on stderr")
+    p.add_argument("--dist-backend", default="nccl",
+                   help="torch.distributed backend for N > 1 (nccl = RCCL).  gloo lets several ranks share one GPU: a "
+                        "rehearsal of the multi-rank control flow on a one-GPU box, not a measurement")
     p.add_argument("--cpu-plumbing-test", action="store_true",
                    help="run only the multi-process plumbing on CPU (gloo) with a no-op step; used by tests")
     return p.parse_args(argv)
@@ -377,8 +385,16 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
     if emulate:
         remote = torch.zeros(S, hidden, dtype=tdtype, device=device)
         reduce_fn = lambda t: t.add_(remote[:t.shape[0]])  # noqa: E731  (stand-in: same bytes, no xGMI)
-    launcher = GraphAllReduce(S, hidden, tdtype, device=device, reduce_fn=reduce_fn)
-    launcher.precapture([S])  # no capture inside the timed loop
+    if not emulate and args.dist_backend != "nccl":
+        # rehearsal on a box without one GPU per rank: the sum goes through host memory (the
+        # backend's own reduction of device tensors is not what is being rehearsed)
+        def reduce_fn(t):  # noqa: F811
+            host = t.cpu()
+            dist.dist.all_reduce(host)
+            t.copy_(host)
+    use_graph = bool(args.tp_graph or emulate)
+    launcher = GraphAllReduce(S, hidden, tdtype, disable_graph=not use_graph, device=device, reduce_fn=reduce_fn)
+    launcher.precapture([S])  # no capture inside the timed loop (a no-op without graphs)
     step_obj = TensorParallelDecodeStep(rank, tp, H, D, w.scale, launcher, pkg.attention_ops, pkg.cache_ops)
     dense_out = torch.empty(S, hidden, dtype=tdtype, device=device) if tp == 1 else None
 
@@ -395,7 +411,9 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         for p in pend[-2:]:  # earlier ones were fenced when their ring buffer came round again
             p.wait()
 
+    progress(dist, f"tp leg: launcher ready ({'graph' if use_graph else 'direct'}); timing")
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
+    progress(dist, f"tp leg timed: {elapsed * 1e3 / args.steps:.3f} ms")
     info = {
         "tp": tp, "heads_per_rank": Hl, "layers": L, "scaling": "strong",
         "value": S * args.steps / elapsed, "unit": "tokens/s", "ms_per_step": elapsed * 1e3 / args.steps,
@@ -404,6 +422,7 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
                 "all-reduce of [batch, hidden] on a side HIP stream (event hand-off, HIP graph replay), "
                 "overlapped with the next layer's cache write and attention",
         "all_reduce_bytes": S * hidden * w.es, "all_reduces_per_step": L if tp > 1 else 0,
+        "all_reduce_launch": "HIP graph replay on the side stream" if use_graph else "direct RCCL call on the side stream",
     }
     if emulate:
         info["emulated"] = ("one GPU ran rank 0's share; the all-reduce is replaced by a local add of a same-sized "
@@ -413,6 +432,7 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         def one(i):
             launcher.launch_async(launcher.next_buffer(S)).wait()
         ts = time_launches(torch, one, 40, warmup=5)
+        progress(dist, "tp leg: isolated all-reduce timed")
         info["all_reduce_isolated_us_median"] = median(ts) * 1e3
         if not emulate:
             info["all_reduce_isolated_us_max_over_ranks"] = dist.max_float(median(ts) * 1e3, device)
@@ -503,10 +523,20 @@ def cpu_baseline(torch, np, args, w, L, attention_ops):
     return res
 
 
+PROGRESS = False
+
+
+def progress(dist, what):
+    if PROGRESS:
+        print(f"# [rank {dist.rank}] {what}", file=sys.stderr, flush=True)
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.cpu_plumbing_test:
         return cpu_plumbing_main(args)
+    global PROGRESS
+    PROGRESS = args.progress
 
     import numpy as np
     import torch
@@ -517,10 +547,11 @@ def main(argv=None):
     S, CTX, B = args.batch, args.ctx, args.block_size
     tdtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[args.dtype]
 
-    dist = Dist("nccl")
+    dist = Dist(args.dist_backend)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(dist.local_rank)
-    device = torch.device("cuda", dist.local_rank)
+    dev_index = dist.local_rank % torch.cuda.device_count()  # one rank per GPU; ranks wrap only in a gloo rehearsal
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     pkg = __graft_entry__.load_package()
     attention_ops, cache_ops = pkg.attention_ops, pkg.cache_ops
     torch.manual_seed(0)
@@ -568,8 +599,10 @@ def main(argv=None):
                 w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, B, CTX,
                 workspace, l > 0, w.total_ctx)
 
+    progress(dist, "inputs resident; timing the replica step")
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     units = dist.sum_float(float(S * args.steps), device)
+    progress(dist, f"replica step timed: {elapsed * 1e3 / args.steps:.3f} ms")
 
     extra = {}
     # ---- roofline of the dominant kernel (decode attention) ------------------------------------
@@ -608,8 +641,13 @@ def main(argv=None):
 
     # ---- N > 1: the head-sharded form measured in the same process ---------------------------------
     if dist.active and not args.no_tp_leg and H % dist.world == 0:
-        tp_elapsed, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w)
-        extra["tp"] = info
+        # an extra measurement: whatever goes wrong in it must not cost the line above
+        progress(dist, "head-sharded leg")
+        try:
+            tp_elapsed, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w)
+            extra["tp"] = info
+        except Exception as e:  # noqa: BLE001
+            extra["tp"] = {"error": f"{type(e).__name__}: {e}"[:500]}
 
     # ---- CPU baseline --------------------------------------------------------------------------------
     if not args.no_cpu_baseline and dist.rank == 0 and dist.world == 1:
