@@ -422,7 +422,7 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
                 "all-reduce of [batch, hidden] on a side HIP stream (event hand-off, HIP graph replay), "
                 "overlapped with the next layer's cache write and attention",
         "all_reduce_bytes": S * hidden * w.es, "all_reduces_per_step": L if tp > 1 else 0,
-        "all_reduce_launch": "HIP graph replay on the side stream" if use_graph else "direct RCCL call on the side stream",
+        "all_reduce_launch": "HIP graph replay on the side stream" if use_graph else f"direct {args.dist_backend} collective on the side stream",
     }
     if emulate:
         info["emulated"] = ("one GPU ran rank 0's share; the all-reduce is replaced by a local add of a same-sized "
