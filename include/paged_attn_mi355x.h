@@ -180,6 +180,54 @@ int pa_single_query_cached_kv_attention_static(
     int dtype, void* stream);
 
 /*
+ * A decode step's two cache-side operations in one launch: reshape_and_cache
+ * of every sequence's new token, then single_query_cached_kv_attention over
+ * the context that now ends with it.  Replaces the generation branch of
+ * PagedAttention.forward (vllm/model_executor/layers/attention.py:134-161),
+ * which runs the two kernels back to back (csrc/cache_kernels.cu:186-224,
+ * csrc/attention/attention_kernels.cu:332-401).
+ *
+ *   key, value   [num_seqs, num_heads, head_size], row strides in elements:
+ *                the new token of each sequence
+ *   context_lens count the new token.  Its place is the last position of the
+ *                context: block block_tables[seq][(context_lens[seq] - 1) /
+ *                block_size], offset (context_lens[seq] - 1) % block_size —
+ *                the slot the reference's worker computes for a generation
+ *                token (vllm/worker/worker.py:183-190); there is no
+ *                slot_mapping argument.
+ *
+ * The workgroup that reads a sequence's last block puts the new key and value
+ * in place in registers, uses them, and writes them to the caches (the key as
+ * 16-byte vectors, the value tile whole), which saves the separate launch and
+ * its read-modify-write of every last block.  That pays for SMALL launches
+ * only.  Measured on MI355X per layer, 32 heads x 128, 1024 tokens, against
+ * the two calls: 1 sequence 18.4 -> 11.5 us, 4: 21.3 -> 19.6, 16: 48.1 -> 45.5,
+ * but 32: 93.7 -> 96.8, 128: 333 -> 399, 256: 657 -> 731 — once the launch
+ * saturates HBM with reads, stores trickling in all through it cost more than
+ * the same stores in a launch of their own.  Callers should use it up to a
+ * few hundred (sequence, head) rows and keep the two calls beyond.
+ * `out` and both caches end up bit-identical to pa_reshape_and_cache followed
+ * by pa_single_query_cached_kv_attention_planned on the same arguments.  The
+ * last block of a sequence must not be mapped by another sequence of the batch
+ * (the reference's block manager copies a shared last block before appending:
+ * vllm/core/block_manager.py:139-160), and nothing else may write the caches
+ * while the call is in flight.  A sequence with context_lens[seq] == 0, or
+ * whose context exceeds the table's width, gets nothing written.
+ * workspace / workspace_bytes / total_context_len as for the _planned form;
+ * workspace may be NULL (no partitions, rows in batch order).  plan_ready:
+ * 0 = make the plan, to be shared by later calls; 1 = the plan in the
+ * workspace is ready; -1 = make a plan for this call alone (as the _ws form).
+ */
+int pa_append_single_query_cached_kv_attention(
+    void* out, const void* query, const void* key, const void* value,
+    void* key_cache, void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs,
+    int num_heads, int head_size, int block_size, int max_num_blocks_per_seq,
+    int max_context_len, int64_t q_stride, int64_t key_stride,
+    int64_t value_stride, int dtype, void* workspace, size_t workspace_bytes,
+    int plan_ready, int64_t total_context_len, void* stream);
+
+/*
  * Scatter new key/value vectors into the paged caches.
  * Replaces reshape_and_cache (csrc/cache_kernels.cu:186-224; kernel :143-182).
  *

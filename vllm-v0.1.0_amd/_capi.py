@@ -31,6 +31,7 @@ EXPORTS = (
     "pa_single_query_cached_kv_attention_ws",
     "pa_single_query_cached_kv_attention_planned",
     "pa_single_query_cached_kv_attention_static",
+    "pa_append_single_query_cached_kv_attention",
     "pa_decode_workspace_bytes",
     "pa_multi_query_kv_attention",
     "pa_reshape_and_cache",
@@ -75,6 +76,10 @@ def _load() -> ctypes.CDLL:
     lib.pa_single_query_cached_kv_attention_planned.argtypes = [
         vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, vp, ctypes.c_size_t, i32, i64, vp]
     lib.pa_single_query_cached_kv_attention_planned.restype = i32
+    lib.pa_append_single_query_cached_kv_attention.argtypes = [
+        vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, i64, i64, i64, i32, vp, ctypes.c_size_t, i32,
+        i64, vp]
+    lib.pa_append_single_query_cached_kv_attention.restype = i32
     lib.pa_decode_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     lib.pa_decode_workspace_bytes.restype = ctypes.c_size_t
     lib.pa_multi_query_kv_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, i64, i64, i64, i32, vp]
@@ -187,6 +192,24 @@ def single_query_cached_kv_attention_planned(out, query, key_cache, value_cache,
         block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size, block_tables.shape[1],
         max_context_len, query.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes,
         1 if plan_ready else 0, int(total_context_len), _stream_handle(stream))
+    check(rc)
+
+
+def append_single_query_cached_kv_attention(out, query, key, value, key_cache, value_cache, scale, block_tables,
+                                            context_lens, block_size, max_context_len, workspace=None, plan_ready=0,
+                                            total_context_len=-1, stream=None) -> None:
+    """reshape_and_cache of each sequence's new token (key / value [S, H, D]) at the last position of its
+    context, and the decode attention over that context, in one launch.  plan_ready: 0 make a shared plan,
+    1 plan is ready, -1 plan for this call alone."""
+    S, H, D = query.shape
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    rc = lib.pa_append_single_query_cached_kv_attention(
+        out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
+        value_cache.data_ptr(), float(scale), block_tables.data_ptr(), context_lens.data_ptr(), S, H, D, block_size,
+        block_tables.shape[1], max_context_len, query.stride(0) if S > 0 else 0, key.stride(0) if S > 0 else 0,
+        value.stride(0) if S > 0 else 0, dtype_code(query.dtype), ws_ptr, ws_bytes, int(plan_ready),
+        int(total_context_len), _stream_handle(stream))
     check(rc)
 
 

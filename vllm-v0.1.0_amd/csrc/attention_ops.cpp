@@ -101,6 +101,41 @@ void single_query_cached_kv_attention_planned(
                what);
 }
 
+// Not part of the reference's module.  The generation branch of PagedAttention.forward
+// (vllm/model_executor/layers/attention.py:134-161) in one launch: reshape_and_cache of the
+// step's new token of every sequence, then single_query_cached_kv_attention over the context
+// that now ends with it.  The new token's place is not taken from a slot_mapping: it is the
+// last position of the context, block_tables[seq][(context_lens[seq] - 1) / block_size] at offset
+// (context_lens[seq] - 1) % block_size, which is where the reference's worker puts a generation
+// token (vllm/worker/worker.py:183-190).  key / value: [num_seqs, num_heads, head_size] token rows.
+void reshape_and_cache_single_query_cached_kv_attention(
+    torch::Tensor& out, torch::Tensor& query, torch::Tensor& key, torch::Tensor& value, torch::Tensor& key_cache,
+    torch::Tensor& value_cache, float scale, torch::Tensor& block_tables, torch::Tensor& context_lens, int block_size,
+    int max_context_len, torch::Tensor& workspace, bool plan_ready, int64_t total_context_len) {
+  using namespace pa_shim;
+  const char* what = "reshape_and_cache_single_query_cached_kv_attention";
+  const DecodeShape sh = check_decode_args(what, out, query, key_cache, value_cache, block_tables, context_lens, block_size);
+  TORCH_CHECK(key.is_cuda() && value.is_cuda() && key.scalar_type() == query.scalar_type() &&
+                  value.scalar_type() == query.scalar_type(),
+              what, ": key and value must be on the GPU and of query's data type");
+  check_token_rows(key, "key");
+  check_token_rows(value, "value");
+  TORCH_CHECK(key.sizes() == query.sizes() && value.sizes() == query.sizes(), what, ": query, key and value shapes differ");
+  TORCH_CHECK(workspace.numel() == 0 || (workspace.is_cuda() && workspace.is_contiguous() &&
+                                         workspace.scalar_type() == at::ScalarType::Byte),
+              what, ": workspace must be a contiguous uint8 tensor on the GPU");
+  const size_t ws_bytes = static_cast<size_t>(workspace.numel());
+  PA_DEVICE_GUARD(query);
+  check_status(pa_append_single_query_cached_kv_attention(
+                   out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
+                   value_cache.data_ptr(), scale, block_tables.data_ptr<int>(), context_lens.data_ptr<int>(), sh.num_seqs,
+                   sh.num_heads, sh.head_size, block_size, static_cast<int>(block_tables.size(1)), max_context_len,
+                   sh.num_seqs > 0 ? query.stride(0) : 0, sh.num_seqs > 0 ? key.stride(0) : 0,
+                   sh.num_seqs > 0 ? value.stride(0) : 0, sh.dtype, ws_bytes > 0 ? workspace.data_ptr() : nullptr, ws_bytes,
+                   plan_ready ? 1 : 0, total_context_len, current_stream(query)),
+               what);
+}
+
 // Not part of the reference's module (its prompt attention lives in xformers):
 // the causal per-prompt attention PagedAttention.multi_query_kv_attention needs
 // (vllm/model_executor/layers/attention.py:44-70), with the prompt lengths as
@@ -148,6 +183,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "Bytes of workspace single_query_cached_kv_attention_planned wants for these sizes (0 = none)");
   m.def("single_query_cached_kv_attention_planned", &single_query_cached_kv_attention_planned,
         "single_query_cached_kv_attention with a workspace whose launch plan is shared by the layers of a step");
+  m.def("reshape_and_cache_single_query_cached_kv_attention", &reshape_and_cache_single_query_cached_kv_attention,
+        "reshape_and_cache of every sequence's new token and single_query_cached_kv_attention over the context "
+        "that ends with it, in one launch");
   m.def("multi_query_kv_attention", &multi_query_kv_attention,
         "Causal self-attention inside each prompt of a flat token batch (MI355X matrix-core kernel)");
 }

@@ -232,6 +232,14 @@ struct DecodeArgs {
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [0] the plan's stamp, [1] number of pairs, [2] blocks per partition in force
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
+  // Append form (null = off): the step's new token of every sequence, [num_seqs][num_heads][D]
+  // with these row strides in elements.  Its place is the last position of the context:
+  // block_tables[seq][(ctx - 1) / B], offset (ctx - 1) % B.
+  const void* new_k;
+  const void* new_v;
+  int64_t new_k_stride;
+  int64_t new_v_stride;
+  int new_vec_ok;         // 16-byte loads of the new key rows are possible
 };
 
 // A launch that finds no plan for its sizes in the workspace (never made, or made for another
@@ -531,6 +539,72 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 #endif
   };
 
+  // Append form: the wave that holds the context's last block in registers puts the new
+  // token's key and value into the tile before using it, and writes them to the caches: the
+  // key as the token's D / X 16-byte vectors, the value tile whole (it is in registers anyway,
+  // and whole lines go straight to memory where 2-byte stores would leave partial sectors
+  // behind for the next launch to trip over).  The block being appended to belongs to this
+  // sequence alone (a shared last block is copied before it is written to,
+  // vllm/core/block_manager.py:139-160), and within the launch only this wave reads it.
+  // Measured on MI355X (32 heads x 128, 1024 tokens, per layer, against reshape_and_cache +
+  // this kernel): 1 sequence 18.4 -> 11.5 us, 4: 21.3 -> 19.6, 16: 48.1 -> 45.5; but 32: 93.7 ->
+  // 96.8, 128: 333 -> 399, 256: 657 -> 731: once the launch saturates HBM with reads, stores
+  // trickling in all through it (a row's worth whenever a workgroup ends) cost far more than
+  // the same stores in a launch of their own (35 MB: +70 us inside, 23 us apart; with the
+  // stores left out the append form costs nothing: 633 vs 633 us; the separate launch run
+  // concurrently on a second stream: 675 us).  The callers use this form for small launches only.
+  const int last_blk = (a.new_k != nullptr && ctx > 0 && (ctx - 1) / B < nblk_seq) ? (ctx - 1) / B : -1;
+  auto append_token = [&](Tile& tl) {
+    const int64_t phys = table[last_blk];
+    const int tok = (ctx - 1) % B;
+    char* kp = const_cast<char*>(kbase) + phys * block_stride;
+    char* vp = const_cast<char*>(vbase) + phys * block_stride;
+    const T* nk = static_cast<const T*>(a.new_k) + (int64_t)seq * a.new_k_stride + (int64_t)head * D;
+    const T* nv = static_cast<const T*>(a.new_v) + (int64_t)seq * a.new_v_stride + (int64_t)head * D;
+    if (t == tok) {
+#pragma unroll
+      for (int i = 0; i < NK; i++) {
+        const int dx = j + KJ * i;
+        if (dx < NDX) {
+          u32x4 v;
+          if (a.new_vec_ok) {
+            v = *reinterpret_cast<const u32x4*>(nk + dx * X);
+          } else {
+            T tmp[X];
+#pragma unroll
+            for (int e = 0; e < X; e++) tmp[e] = nk[dx * X + e];
+            v = __builtin_bit_cast(u32x4, tmp);
+          }
+          tl.k[i] = v;
+          __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(kp + i * 1024));
+        }
+      }
+    }
+    const int tvs = tok / X, el = tok % X;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int d = r + RPL * i;
+      if (d < D) {
+        u32x4 v = tl.v[i];
+        if (tv == tvs) {
+          const T val = nv[d];
+          if constexpr (sizeof(T) == 4) {
+            const uint32_t bits = __builtin_bit_cast(uint32_t, val);
+#pragma unroll
+            for (int w = 0; w < 4; w++) v[w] = w == el ? bits : v[w];
+          } else {
+            const uint32_t bits = (uint32_t)__builtin_bit_cast(uint16_t, val);
+            const int sh = (el & 1) * 16;
+#pragma unroll
+            for (int w = 0; w < 4; w++) v[w] = w == (el >> 1) ? ((v[w] & ~(0xffffu << sh)) | (bits << sh)) : v[w];
+          }
+          tl.v[i] = v;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(vp + i * 1024));
+      }
+    }
+  };
+
   float m = -FLT_MAX;  // running maximum (log2 domain)
   float l = 0.f;       // running sum of this lane's own token column
   float acc[NV];
@@ -586,23 +660,37 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 
   // Two register tiles, alternating: the loads of block n+1 are issued before
   // block n is consumed.
+  // Append form: the loop fetches the context's last block like any other but leaves it to
+  // the code behind the loop, which holds the stores (stores inside the loop would make every
+  // wait for a tile wait for them as well: loads and stores share one counter).
   {
     Tile ta, tb;
+    const bool last_here = last_blk >= blk_begin && last_blk < nblk;  // in this workgroup's partition
+    const int nblk_loop = last_here ? last_blk : nblk;
     int blk = blk_begin + wave;
     int it = 0;  // index of blk among this wave's blocks
     if (blk < nblk) load_tile(ta, entry(0));
-    while (blk < nblk) {
+    while (blk < nblk_loop) {
       int nb = blk + NW;
       if (nb < nblk) load_tile(tb, entry(it + 1));
       consume(ta, blk);
       blk = nb;
       it++;
-      if (blk >= nblk) break;
+      if (blk >= nblk_loop) break;
       nb = blk + NW;
       if (nb < nblk) load_tile(ta, entry(it + 1));
       consume(tb, blk);
       blk = nb;
       it++;
+    }
+    if (last_here && blk == last_blk) {  // this wave's turn came to the last block: its tile is the one just fetched
+      if (it & 1) {
+        append_token(tb);
+        consume(tb, blk);
+      } else {
+        append_token(ta);
+        consume(ta, blk);
+      }
     }
   }
 
@@ -1163,11 +1251,20 @@ static size_t workspace_bytes_any(int num_seqs, int num_heads, int head_size, in
   return n;
 }
 
+// The step's new token of every sequence, for the append form: [num_seqs][num_heads][head_size]
+// rows with these strides in elements.
+struct NewTokens {
+  const void* key;
+  const void* value;
+  int64_t key_stride;
+  int64_t value_stride;
+};
+
 static int decode_entry(void* out, const void* query, const void* key_cache, const void* value_cache, float scale,
                         const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads,
                         int head_size, int block_size, int max_num_blocks_per_seq, int max_context_len,
                         int64_t q_stride, int dtype, void* workspace, size_t workspace_bytes, int plan_mode,
-                        int64_t total_context_len, void* stream) {
+                        int64_t total_context_len, void* stream, const NewTokens* new_tokens = nullptr) {
   clear_error();
   PA_REQUIRE(num_seqs >= 0 && num_heads >= 0, "negative num_seqs (%d) or num_heads (%d)", num_seqs, num_heads);
   if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
@@ -1214,6 +1311,23 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   static const int plain_rows = tuning_int("PA_DECODE_PLAIN_ROWS", kPlainOrderRows);  // tuning builds only
   a.plain_order = rows <= plain_rows ? 1 : 0;
   a.plan_tag = 0;
+  a.new_k = nullptr;
+  a.new_v = nullptr;
+  a.new_k_stride = a.new_v_stride = 0;
+  a.new_vec_ok = 0;
+  if (new_tokens != nullptr) {
+    PA_REQUIRE(new_tokens->key && new_tokens->value, "null key / value argument");
+    PA_REQUIRE(new_tokens->key_stride >= (int64_t)num_heads * head_size && new_tokens->value_stride >= (int64_t)num_heads * head_size,
+               "key_stride (%lld) / value_stride (%lld) shorter than a token row of %d x %d elements",
+               (long long)new_tokens->key_stride, (long long)new_tokens->value_stride, num_heads, head_size);
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(new_tokens->key) % es) == 0 && (reinterpret_cast<uintptr_t>(new_tokens->value) % es) == 0,
+               "key / value must be aligned to the element size");
+    a.new_k = new_tokens->key;
+    a.new_v = new_tokens->value;
+    a.new_k_stride = new_tokens->key_stride;
+    a.new_v_stride = new_tokens->value_stride;
+    a.new_vec_ok = aligned16(new_tokens->key) && ((new_tokens->key_stride * (int64_t)es) % 16 == 0) && ((head_size * es) % 16 == 0);
+  }
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len,
@@ -1376,4 +1490,18 @@ extern "C" int pa_single_query_cached_kv_attention_planned(
   return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
                           head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
                           workspace_bytes, plan_ready ? pa::kPlanReady : pa::kPlanShared, total_context_len, stream);
+}
+
+extern "C" int pa_append_single_query_cached_kv_attention(
+    void* out, const void* query, const void* key, const void* value, void* key_cache, void* value_cache, float scale,
+    const int32_t* block_tables, const int32_t* context_lens, int num_seqs, int num_heads, int head_size,
+    int block_size, int max_num_blocks_per_seq, int max_context_len, int64_t q_stride, int64_t key_stride,
+    int64_t value_stride, int dtype, void* workspace, size_t workspace_bytes, int plan_ready,
+    int64_t total_context_len, void* stream) {
+  const pa::NewTokens nt = {key, value, key_stride, value_stride};
+  return pa::decode_entry(out, query, key_cache, value_cache, scale, block_tables, context_lens, num_seqs, num_heads,
+                          head_size, block_size, max_num_blocks_per_seq, max_context_len, q_stride, dtype, workspace,
+                          workspace != nullptr ? workspace_bytes : 0,
+                          plan_ready > 0 ? pa::kPlanReady : (plan_ready < 0 ? pa::kPlanPerCall : pa::kPlanShared),
+                          total_context_len, stream, &nt);
 }

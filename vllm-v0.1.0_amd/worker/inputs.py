@@ -152,4 +152,7 @@ def prepare_inputs(
     meta._staging = host
     # known here on the host, and useful to the attention operator's launch plan
     meta.total_context_len = int(ctx.sum()) if num_gen else 0
+    # every generation token's slot is the last position of its context in its own block table
+    # (computed so above): the attention layer may derive it there instead of reading slot_mapping
+    meta.generation_slots_follow_tables = True
     return tokens_t, positions_t, meta
