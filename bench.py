@@ -128,6 +128,10 @@ def parse_args(argv=None):
                    help="tensor-parallel legs: replay the all-reduce from a HIP graph captured on the side stream "
                         "(default: direct RCCL calls on the side stream; the graph path has only been exercised with a "
                         "stand-in collective on one GPU)")
+    p.add_argument("--tp-collective", choices=["backend", "push"], default="backend",
+                   help="tensor-parallel legs: 'backend' = all_reduce of --dist-backend (RCCL); 'push' = this package's "
+                        "one-shot all-reduce over peer-mapped inboxes (worker/push_all_reduce.py), which also runs with "
+                        "several ranks on one GPU")
     p.add_argument("--roofline-only", action="store_true",
                    help="launch nothing but isolated decode kernels (5 warm-ups + 40 timed): the command to put "
                         "under rocprofv3 --kernel-trace so that its per-dispatch median reproduces roofline.frac")
@@ -385,7 +389,12 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
     if emulate:
         remote = torch.zeros(S, hidden, dtype=tdtype, device=device)
         reduce_fn = lambda t: t.add_(remote[:t.shape[0]])  # noqa: E731  (stand-in: same bytes, no xGMI)
-    if not emulate and args.dist_backend != "nccl":
+    push = None
+    if not emulate and args.tp_collective == "push" and tp > 1:
+        from vllm_amd.worker import PushAllReduce
+        push = PushAllReduce(S * hidden * w.es, device=device)  # handles exchanged over the process group
+        reduce_fn = push
+    elif not emulate and args.dist_backend != "nccl":
         # rehearsal on a box without one GPU per rank: the sum goes through host memory (the
         # backend's own reduction of device tensors is not what is being rehearsed)
         def reduce_fn(t):  # noqa: F811
@@ -414,15 +423,20 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
     progress(dist, f"tp leg: launcher ready ({'graph' if use_graph else 'direct'}); timing")
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     progress(dist, f"tp leg timed: {elapsed * 1e3 / args.steps:.3f} ms")
+    coll = ("one-shot push" if push is not None else "stand-in" if emulate else
+            "RCCL" if args.dist_backend == "nccl" else f"{args.dist_backend} (host-staged)")
     info = {
         "tp": tp, "heads_per_rank": Hl, "layers": L, "scaling": "strong",
         "value": S * args.steps / elapsed, "unit": "tokens/s", "ms_per_step": elapsed * 1e3 / args.steps,
         "step": "per layer: reshape_and_cache + single_query_cached_kv_attention on the local heads, row-parallel "
-                "o_proj matmul [batch, heads/tp * head_size] x [.., hidden] into the all-reduce buffer, RCCL "
-                "all-reduce of [batch, hidden] on a side HIP stream (event hand-off, HIP graph replay), "
-                "overlapped with the next layer's cache write and attention",
+                "o_proj matmul [batch, heads/tp * head_size] x [.., hidden] into the all-reduce buffer, "
+                f"{coll} all-reduce of [batch, hidden] on a side HIP stream (event hand-off"
+                f"{', HIP graph replay' if use_graph else ''}), overlapped with the next layer's cache write and attention",
         "all_reduce_bytes": S * hidden * w.es, "all_reduces_per_step": L if tp > 1 else 0,
-        "all_reduce_launch": "HIP graph replay on the side stream" if use_graph else f"direct {args.dist_backend} collective on the side stream",
+        "all_reduce_launch": "HIP graph replay on the side stream" if use_graph else "direct call on the side stream",
+        "all_reduce_collective": ("one-shot push over peer-mapped inboxes (pa_comm_all_reduce)" if push is not None else
+                                  "local stand-in" if emulate else f"{args.dist_backend} all_reduce"
+                                  + ("" if args.dist_backend == "nccl" else " staged through host memory")),
     }
     if emulate:
         info["emulated"] = ("one GPU ran rank 0's share; the all-reduce is replaced by a local add of a same-sized "
@@ -436,6 +450,11 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         info["all_reduce_isolated_us_median"] = median(ts) * 1e3
         if not emulate:
             info["all_reduce_isolated_us_max_over_ranks"] = dist.max_float(median(ts) * 1e3, device)
+    if push is not None:
+        done, gave_up = push.status()
+        info["push_reduces_done"], info["push_waits_given_up"] = done, gave_up
+        dist.barrier()
+        push.close()
     return elapsed, info, w
 
 

@@ -379,6 +379,58 @@ int pa_rms_norm(
 int pa_silu_and_mul(
     void* out, const void* input, int num_tokens, int d, int dtype, void* stream);
 
+/*
+ * One-shot all-reduce (sum) for the small messages of tensor parallelism: the
+ * partial results of a row-parallel matmul, which the reference sums with
+ * NCCL's all-reduce replayed from a CUDA graph
+ * (vllm/model_executor/parallel_utils/parallel_state.py:506-556; call site
+ * parallel_utils/tensor_parallel/layers.py:416-426; group set-up
+ * vllm/worker/worker.py:286-301).  On an MI355X node every pair of GPUs has its
+ * own xGMI link: each rank pushes its buffer into an inbox on every peer over
+ * all links at once, raises a flag there, waits for its peers' flags and sums
+ * the contributions from local memory, in rank order and in fp32, so that
+ * all ranks end with bit-identical sums.  One kernel launch per reduce, no
+ * host involvement, capturable in a HIP graph (the reduce's sequence number
+ * lives in device memory).  Meant for messages up to a few MiB and at most 8
+ * ranks of one node; larger messages belong to RCCL.
+ *
+ * These are the only entry points of the library that allocate, free or
+ * synchronise, and only in create / connect / status / destroy:
+ *
+ *   pa_comm_create   on the current device: control words and an inbox of
+ *                    2 x world x max_bytes; writes PA_COMM_HANDLE_BYTES of IPC
+ *                    handles to handles_out for peers in other processes.
+ *   pa_comm_connect  all_handles = the world's handle blobs in rank order
+ *                    (exchanged by the caller, e.g. with an all_gather over
+ *                    its process group); maps every peer's memory.
+ *   pa_comm_connect_local  the same for communicators that live in this
+ *                    process (one per device, or several on one device): takes
+ *                    the communicators themselves, in rank order.
+ *   Every rank must have connected before any rank's first reduce (the caller
+ *   places a barrier of its process group in between).
+ *   pa_comm_all_reduce  data[count] of dtype, 16-byte aligned, count x element
+ *                    size a multiple of 16 and at most max_bytes: summed over
+ *                    the ranks in place, asynchronously on `stream`.  All ranks
+ *                    must issue the same sequence of reduces.  Reduces of one
+ *                    communicator must not overlap in time (one stream, or
+ *                    event-ordered).  A rank whose peers do not arrive within
+ *                    two seconds gives up the wait, finishes the launch with a
+ *                    meaningless result and counts a timeout.
+ *   pa_comm_status   synchronous read-back: reduces completed, timeouts.
+ */
+#define PA_COMM_HANDLE_BYTES 128
+
+typedef struct pa_comm pa_comm;
+
+int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** comm,
+                   unsigned char* handles_out);
+int pa_comm_connect(pa_comm* comm, const unsigned char* all_handles);
+int pa_comm_connect_local(pa_comm* comm, pa_comm* const* all_comms);
+int pa_comm_all_reduce(pa_comm* comm, void* data, size_t count, int dtype,
+                       void* stream);
+int pa_comm_status(pa_comm* comm, uint32_t* reduces_done, uint32_t* timeouts);
+int pa_comm_destroy(pa_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

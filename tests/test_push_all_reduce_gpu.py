@@ -1,0 +1,120 @@
+"""GPU tests of the one-shot all-reduce (pa_comm_*, worker/push_all_reduce.py).
+
+A one-GPU box is enough to check the algorithm: several ranks of a group live on the same
+card, each with a stream of its own (peers reached by pointer), or in processes of their own
+(peers reached through IPC mappings).  Expected value: the ranks' buffers added in rank order
+in fp32, rounded once — bit-exact, and identical on every rank."""
+import os
+import textwrap
+
+import pytest
+
+from tests.test_all_reduce import _run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(parts, dtype):
+    import torch
+    acc = torch.zeros(parts[0].shape, dtype=torch.float32, device=parts[0].device)
+    for p in parts:
+        acc = acc + p.float()
+    return acc.to(dtype)
+
+
+def _bits(t):
+    import torch
+    return t.view(torch.int16 if t.element_size() == 2 else torch.int32)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_ranks_on_one_gpu_by_pointer(pkg, world):
+    import torch
+    from vllm_amd.worker import PushAllReduce
+    dev = torch.device("cuda:0")
+    max_bytes = 1 << 20
+    ranks = PushAllReduce.local_ranks(world, max_bytes)
+    streams = [torch.cuda.Stream(dev) for _ in range(world)]
+    try:
+        g = torch.Generator(device="cpu").manual_seed(world)
+        k = 0
+        for dtype in (torch.float16, torch.bfloat16, torch.float32):
+            es = torch.tensor([], dtype=dtype).element_size()
+            for n in (8, 4096, 40 * 4096, max_bytes // es, 24):   # odd and even reduces, growing and shrinking
+                parts = [torch.randn(n, generator=g).to(dtype).to(dev) for _ in range(world)]
+                want = _expected(parts, dtype)
+                torch.cuda.synchronize()
+                for r in range(world):
+                    with torch.cuda.stream(streams[r]):
+                        ranks[r](parts[r])
+                torch.cuda.synchronize()
+                k += 1
+                if any(r.status()[1] for r in ranks):
+                    # the ranks' kernels wait for one another: they must be on the GPU together, which
+                    # streams of one process are only if the runtime gave them hardware queues of their own
+                    pytest.skip(f"the {world} streams did not run concurrently (reduce {k}: waits given up "
+                                f"{[r.status()[1] for r in ranks]}); the multi-process test covers {world} ranks")
+                for r in range(world):
+                    assert torch.equal(_bits(parts[r]), _bits(want)), (dtype, n, r)
+        for r in ranks:
+            assert r.status() == (k, 0)
+        with pytest.raises(pkg._capi.PagedAttnError, match="exceeds"):
+            ranks[0](torch.zeros(max_bytes // 2 + 8, dtype=torch.float32, device=dev))
+        with pytest.raises(pkg._capi.PagedAttnError, match="multiple of 16"):
+            ranks[0](torch.zeros(4, dtype=torch.float16, device=dev))
+    finally:
+        for r in ranks:
+            r.close()
+
+
+_IPC_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.getcwd())
+    import torch, torch.distributed as dist
+    import __graft_entry__
+    __graft_entry__.load_package()
+    from vllm_amd.worker import GraphAllReduce, PushAllReduce
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)                       # every rank on the one card
+    dev = torch.device("cuda:0")
+    tokens, hidden = 64, 512
+    reduce = PushAllReduce(tokens * hidden * 2)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for step, n in enumerate((64, 8, 64, 24)):
+        parts = [torch.randn(n, hidden, generator=g).half() for _ in range(world)]   # same on every rank
+        want = sum((p.float() for p in parts[1:]), parts[0].float()).half()
+        x = parts[rank].to(dev)
+        reduce(x)
+        torch.cuda.synchronize()
+        assert torch.equal(x.cpu().view(torch.int16), want.view(torch.int16)), (rank, step)
+    # inside the launcher, as the tensor-parallel step uses it: side stream, events, one HIP graph per
+    # (buffer, token count) captured on first use with live partial sums, replayed with fresh ones
+    launcher = GraphAllReduce(tokens, hidden, torch.float16, device=dev, reduce_fn=reduce)
+    assert not launcher.disable_graph
+    for step, n in enumerate((16, 64, 16, 64, 16, 64, 40)):
+        parts = [torch.randn(n, hidden, generator=g).half() for _ in range(world)]
+        want = sum((p.float() for p in parts[1:]), parts[0].float()).half()
+        buf = launcher.next_buffer(n)
+        buf.copy_(parts[rank])
+        pending = launcher.launch_async(buf)
+        torch.cuda._sleep(200000)                      # the caller's stream has other work meanwhile
+        y = pending.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(y.cpu().view(torch.int16), want.view(torch.int16)), (rank, "launcher", step)
+    # 16 and 40 tokens met buffer 0 of the ring, 64 buffer 1: three graphs, each captured after one warm-up reduce
+    assert sorted(launcher.graphs) == [(0, 16), (0, 40), (1, 64)], sorted(launcher.graphs)
+    done, timeouts = reduce.status()
+    assert (done, timeouts) == (4 + 7 + 3, 0), (rank, done, timeouts)
+    dist.barrier()
+    reduce.close()
+    print(f"rank {rank} ok", flush=True)
+""")
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_in_processes_of_their_own_through_ipc(pkg, world):
+    res = _run_ranks(_IPC_WORKER, world, timeout=240, env_extra={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    for r in range(world):
+        assert f"rank {r} ok" in res.stdout

@@ -42,6 +42,12 @@ EXPORTS = (
     "pa_rotary_embedding_neox",
     "pa_rms_norm",
     "pa_silu_and_mul",
+    "pa_comm_create",
+    "pa_comm_connect",
+    "pa_comm_connect_local",
+    "pa_comm_all_reduce",
+    "pa_comm_status",
+    "pa_comm_destroy",
 )
 
 
@@ -100,6 +106,18 @@ def _load() -> ctypes.CDLL:
     lib.pa_rms_norm.restype = i32
     lib.pa_silu_and_mul.argtypes = [vp, vp, i32, i32, i32, vp]
     lib.pa_silu_and_mul.restype = i32
+    lib.pa_comm_create.argtypes = [i32, i32, ctypes.c_size_t, ctypes.POINTER(vp), vp]
+    lib.pa_comm_create.restype = i32
+    lib.pa_comm_connect.argtypes = [vp, vp]
+    lib.pa_comm_connect.restype = i32
+    lib.pa_comm_connect_local.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.pa_comm_connect_local.restype = i32
+    lib.pa_comm_all_reduce.argtypes = [vp, vp, ctypes.c_size_t, i32, vp]
+    lib.pa_comm_all_reduce.restype = i32
+    lib.pa_comm_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    lib.pa_comm_status.restype = i32
+    lib.pa_comm_destroy.argtypes = [vp]
+    lib.pa_comm_destroy.restype = i32
     if lib.pa_abi_version() != PA_ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.pa_abi_version()} != {PA_ABI_VERSION}")
     return lib
@@ -305,3 +323,45 @@ def silu_and_mul(out, input, stream=None) -> None:
     rc = lib.pa_silu_and_mul(out.data_ptr(), input.data_ptr(), input.shape[0], input.shape[1] // 2,
                              dtype_code(input.dtype), _stream_handle(stream))
     check(rc)
+
+
+# ---- one-shot all-reduce communicator ---------------------------------------------
+
+COMM_HANDLE_BYTES = 128
+
+
+def comm_create(rank: int, world: int, max_bytes: int):
+    """On the current device.  Returns (communicator handle, bytes of IPC handles for peers in other processes)."""
+    comm = ctypes.c_void_p()
+    blob = (ctypes.c_ubyte * COMM_HANDLE_BYTES)()
+    check(lib.pa_comm_create(int(rank), int(world), int(max_bytes), ctypes.byref(comm), blob))
+    return comm, bytes(blob)
+
+
+def comm_connect(comm, all_handles: Sequence[bytes]) -> None:
+    """all_handles: every rank's handle bytes, in rank order."""
+    blob = b"".join(all_handles)
+    buf = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
+    check(lib.pa_comm_connect(comm, buf))
+
+
+def comm_connect_local(comm, all_comms) -> None:
+    """all_comms: the communicators of all ranks (they live in this process), in rank order."""
+    arr = (ctypes.c_void_p * len(all_comms))(*[c.value for c in all_comms])
+    check(lib.pa_comm_connect_local(comm, arr))
+
+
+def comm_all_reduce(comm, tensor, stream=None) -> None:
+    """In-place sum of a contiguous tensor over the communicator's ranks, on `stream` (default: torch's current)."""
+    check(lib.pa_comm_all_reduce(comm, tensor.data_ptr(), tensor.numel(), dtype_code(tensor.dtype), _stream_handle(stream)))
+
+
+def comm_status(comm):
+    """(reduces completed, timeouts); synchronises with the device."""
+    done, timeouts = ctypes.c_uint32(), ctypes.c_uint32()
+    check(lib.pa_comm_status(comm, ctypes.byref(done), ctypes.byref(timeouts)))
+    return done.value, timeouts.value
+
+
+def comm_destroy(comm) -> None:
+    check(lib.pa_comm_destroy(comm))

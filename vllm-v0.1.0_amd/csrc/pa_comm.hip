@@ -1,0 +1,366 @@
+// One-shot all-reduce for the small messages of tensor parallelism on MI355X (gfx950).
+//
+// The reference sums the partial results of every row-parallel matmul over the tensor-parallel
+// group with NCCL's all-reduce replayed from a CUDA graph
+// (vllm/model_executor/parallel_utils/parallel_state.py:506-556; call site
+// parallel_utils/tensor_parallel/layers.py:416-426).  Those messages are small — a decode step
+// reduces [256, 4096] fp16 = 2 MiB twice per layer, a small batch a few KiB — and on an MI355X
+// node every pair of GPUs has an xGMI link of its own, so a ring (2 (N - 1) dependent hops over
+// one link at a time) is the wrong shape for them.  Here every rank PUSHES its buffer straight
+// into an inbox on every peer, all N - 1 links at once, raises a flag there, waits for the N - 1
+// flags raised at home, and sums the N contributions out of local memory:
+//
+//   one launch, one hop, no second barrier.
+//
+// Why one barrier is enough: the inboxes are double buffered by the parity of the reduce's
+// sequence number.  A peer can only start pushing reduce k + 1 (other parity) while this rank
+// still sums reduce k, never k + 2: reduce k + 1 does not finish anywhere before this rank has
+// raised its k + 1 flags, which it does only after its k sums are done.  The result is written
+// in place over the caller's buffer, which no peer ever touches.  Every rank adds the N
+// contributions in rank order in fp32, so all ranks hold bit-identical sums.
+//
+// Memory: peers' inboxes and flag words are reached through IPC mappings (one process per GPU)
+// or plain pointers (several communicators in one process).  Flags live in uncached memory and
+// are written / read with system-scope release / acquire; the data stores are ordinary vector
+// stores made visible by the release fence every wave executes before the workgroup counts
+// itself as arrived.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
+// peers never arrive gives up, counts a timeout that pa_comm_status reports, and finishes the
+// launch with a meaningless result rather than hanging the GPU.
+//
+// The sequence number lives in device memory, not in the kernel arguments, so a captured launch
+// can be replayed from a HIP graph.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <new>
+
+#include "pa_common.h"
+
+namespace pa {
+
+constexpr int kCommMaxRanks = 8;
+constexpr int kCommThreads = 256;
+constexpr int kCommMaxWorkgroups = 128;
+constexpr unsigned long long kWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+
+// control words of a rank, in uncached device memory
+enum : int { kFlag0 = 0, kSeq = kCommMaxRanks, kArrived, kFinished, kTimeouts, kCtrlWords = 16 };
+
+struct CommArgs {
+  uint32_t* ctrl[kCommMaxRanks];  // every rank's control words, as mapped here
+  char* inbox[kCommMaxRanks];     // every rank's inbox [2][world][slot_bytes], as mapped here
+  void* data;                     // this rank's buffer: contribution in, sum out
+  size_t slot_bytes;
+  size_t n16;                     // 16-byte vectors in the message
+  int rank;
+  int world;
+};
+
+template <typename T> struct Acc;
+template <> struct Acc<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void add(float* acc, u32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] += __uint_as_float(v[i]);
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* acc) {
+    return u32x4{__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+  }
+};
+template <> struct Acc<_Float16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void add(float* acc, u32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const f16x2 h = __builtin_bit_cast(f16x2, (uint32_t)v[i]);
+      acc[2 * i] += (float)h[0];
+      acc[2 * i + 1] += (float)h[1];
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* acc) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const f16x2 h = {(_Float16)acc[2 * i], (_Float16)acc[2 * i + 1]};
+      r[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return r;
+  }
+};
+template <> struct Acc<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void add(float* acc, u32x4 v) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      acc[2 * i] += __uint_as_float((uint32_t)v[i] << 16);
+      acc[2 * i + 1] += __uint_as_float((uint32_t)v[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* acc) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const bf16x2 h = {(__bf16)acc[2 * i], (__bf16)acc[2 * i + 1]};
+      r[i] = __builtin_bit_cast(uint32_t, h);
+    }
+    return r;
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const CommArgs a) {
+  __shared__ int last_to_arrive;
+  const int tid = threadIdx.x;
+  uint32_t* ctrl = a.ctrl[a.rank];
+  // written by the last workgroup of the previous reduce (or zero): stable for this whole launch
+  const uint32_t k = __hip_atomic_load(&ctrl[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const size_t parity_off = (size_t)(k & 1u) * a.world * a.slot_bytes;
+  u32x4* data = static_cast<u32x4*>(a.data);
+  const size_t stride = (size_t)gridDim.x * kCommThreads;
+
+  // 1. push this rank's contribution into slot `rank` of every peer's inbox
+  for (size_t i = (size_t)blockIdx.x * kCommThreads + tid; i < a.n16; i += stride) {
+    const u32x4 v = data[i];
+    for (int p = 0; p < a.world; p++) {
+      if (p == a.rank) continue;
+      *reinterpret_cast<u32x4*>(a.inbox[p] + parity_off + (size_t)a.rank * a.slot_bytes + i * 16) = v;
+    }
+  }
+  // every wave: its stores have reached the peers before the workgroup counts as arrived
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(&ctrl[kArrived], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last_to_arrive = before + 1u == gridDim.x;
+  }
+  __syncthreads();
+  if (last_to_arrive) {
+    // the whole contribution is out: tell every peer
+    if (tid < a.world && tid != a.rank)
+      __hip_atomic_store(&a.ctrl[tid][kFlag0 + a.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(&ctrl[kArrived], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // 2. wait for every peer's contribution to this reduce (or a later one: flags only grow)
+  if (tid < a.world && tid != a.rank) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int32_t)(__hip_atomic_load(&ctrl[kFlag0 + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+      if (wall_clock64() - t0 > kWaitTicks) {
+        __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every wave: nothing read below comes from a stale cache line
+
+  // 3. sum the contributions in rank order, in place over this rank's own
+  const char* mine = a.inbox[a.rank] + parity_off;
+  for (size_t i = (size_t)blockIdx.x * kCommThreads + tid; i < a.n16; i += stride) {
+    float acc[Acc<T>::N];
+#pragma unroll
+    for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
+    for (int p = 0; p < a.world; p++) {
+      const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + i * 16);
+      Acc<T>::add(acc, v);
+    }
+    data[i] = Acc<T>::pack(acc);
+  }
+
+  // 4. the last workgroup to finish closes the reduce
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(&ctrl[kFinished], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == gridDim.x) {
+      __hip_atomic_store(&ctrl[kFinished], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctrl[kSeq], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace pa
+
+struct pa_comm {
+  int rank = 0;
+  int world = 1;
+  int device = 0;
+  size_t max_bytes = 0;
+  size_t slot_bytes = 0;
+  uint32_t* ctrl = nullptr;  // own control words
+  char* inbox = nullptr;     // own inbox
+  bool connected = false;
+  bool peers_by_ipc = false;
+  uint32_t* peer_ctrl[pa::kCommMaxRanks] = {};
+  char* peer_inbox[pa::kCommMaxRanks] = {};
+};
+
+namespace pa {
+
+#define PA_COMM_HIP(call, what)                                                           \
+  do {                                                                                    \
+    hipError_t pa_e_ = (call);                                                            \
+    if (pa_e_ != hipSuccess) return fail(PA_ERR_HIP, "%s: %s", what, hipGetErrorString(pa_e_)); \
+  } while (0)
+
+static int comm_free(pa_comm* c) {
+  if (c == nullptr) return PA_OK;
+  if (c->peers_by_ipc) {
+    for (int p = 0; p < c->world; p++) {
+      if (p == c->rank) continue;
+      if (c->peer_ctrl[p] != nullptr) (void)hipIpcCloseMemHandle(c->peer_ctrl[p]);
+      if (c->peer_inbox[p] != nullptr) (void)hipIpcCloseMemHandle(c->peer_inbox[p]);
+    }
+  }
+  if (c->ctrl != nullptr) (void)hipFree(c->ctrl);
+  if (c->inbox != nullptr) (void)hipFree(c->inbox);
+  delete c;
+  return PA_OK;
+}
+
+}  // namespace pa
+
+extern "C" int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** comm, unsigned char* handles_out) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(comm != nullptr && handles_out != nullptr, "pa_comm_create: null pointer argument");
+  PA_REQUIRE(world >= 1 && world <= kCommMaxRanks && rank >= 0 && rank < world,
+             "pa_comm_create: rank %d of %d (at most %d ranks)", rank, world, kCommMaxRanks);
+  PA_REQUIRE(max_bytes > 0, "pa_comm_create: max_bytes must be positive");
+  pa_comm* c = new (std::nothrow) pa_comm();
+  if (c == nullptr) return fail(PA_ERR_HIP, "pa_comm_create: out of host memory");
+  c->rank = rank;
+  c->world = world;
+  c->max_bytes = max_bytes;
+  c->slot_bytes = (max_bytes + 255) / 256 * 256;
+  memset(handles_out, 0, PA_COMM_HANDLE_BYTES);
+  hipError_t e = hipGetDevice(&c->device);
+  if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->ctrl), 256, hipDeviceMallocUncached);
+  if (e == hipSuccess) e = hipMemset(c->ctrl, 0, 256);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->inbox), 2 * (size_t)world * c->slot_bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    comm_free(c);
+    return fail(PA_ERR_HIP, "pa_comm_create: allocating the control words and a %zu-byte inbox: %s",
+                2 * (size_t)world * ((max_bytes + 255) / 256 * 256), hipGetErrorString(e));
+  }
+  // Handles for peers in other processes.  A communicator whose peers live in this process
+  // (pa_comm_connect_local) never needs them: failing to export is not an error here.
+  static_assert(2 * sizeof(hipIpcMemHandle_t) <= PA_COMM_HANDLE_BYTES, "handle blob too small");
+  hipIpcMemHandle_t h[2];
+  if (hipIpcGetMemHandle(&h[0], c->ctrl) == hipSuccess && hipIpcGetMemHandle(&h[1], c->inbox) == hipSuccess) {
+    memcpy(handles_out, h, sizeof(h));
+  } else {
+    (void)hipGetLastError();
+  }
+  *comm = c;
+  return PA_OK;
+}
+
+extern "C" int pa_comm_connect(pa_comm* c, const unsigned char* all_handles) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(c != nullptr && all_handles != nullptr, "pa_comm_connect: null pointer argument");
+  PA_REQUIRE(!c->connected, "pa_comm_connect: already connected");
+  for (int p = 0; p < c->world; p++) {
+    if (p == c->rank) {
+      c->peer_ctrl[p] = c->ctrl;
+      c->peer_inbox[p] = c->inbox;
+      continue;
+    }
+    hipIpcMemHandle_t h[2];
+    memcpy(h, all_handles + (size_t)p * PA_COMM_HANDLE_BYTES, sizeof(h));
+    bool blank = true;
+    for (size_t i = 0; i < sizeof(h); i++) blank = blank && reinterpret_cast<const unsigned char*>(h)[i] == 0;
+    PA_REQUIRE(!blank, "pa_comm_connect: rank %d exported no handle (hipIpcGetMemHandle failed there)", p);
+    c->peers_by_ipc = true;
+    PA_COMM_HIP(hipIpcOpenMemHandle(reinterpret_cast<void**>(&c->peer_ctrl[p]), h[0], hipIpcMemLazyEnablePeerAccess),
+                "pa_comm_connect: hipIpcOpenMemHandle(control words)");
+    PA_COMM_HIP(hipIpcOpenMemHandle(reinterpret_cast<void**>(&c->peer_inbox[p]), h[1], hipIpcMemLazyEnablePeerAccess),
+                "pa_comm_connect: hipIpcOpenMemHandle(inbox)");
+  }
+  c->connected = true;
+  return PA_OK;
+}
+
+extern "C" int pa_comm_connect_local(pa_comm* c, pa_comm* const* all) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(c != nullptr && all != nullptr, "pa_comm_connect_local: null pointer argument");
+  PA_REQUIRE(!c->connected, "pa_comm_connect_local: already connected");
+  for (int p = 0; p < c->world; p++) {
+    PA_REQUIRE(all[p] != nullptr && all[p]->rank == p && all[p]->world == c->world && all[p]->slot_bytes == c->slot_bytes,
+               "pa_comm_connect_local: entry %d is not rank %d of a communicator of the same shape", p, p);
+    if (all[p]->device != c->device) {
+      int can = 0;
+      PA_COMM_HIP(hipDeviceCanAccessPeer(&can, c->device, all[p]->device), "pa_comm_connect_local: hipDeviceCanAccessPeer");
+      PA_REQUIRE(can, "pa_comm_connect_local: device %d cannot access device %d", c->device, all[p]->device);
+      hipError_t e = hipDeviceEnablePeerAccess(all[p]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(PA_ERR_HIP, "pa_comm_connect_local: hipDeviceEnablePeerAccess: %s", hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+    c->peer_ctrl[p] = all[p]->ctrl;
+    c->peer_inbox[p] = all[p]->inbox;
+  }
+  c->connected = true;
+  return PA_OK;
+}
+
+extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtype, void* stream) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(c != nullptr, "pa_comm_all_reduce: null communicator");
+  if (dtype != PA_DTYPE_F32 && dtype != PA_DTYPE_F16 && dtype != PA_DTYPE_BF16)
+    return fail(PA_ERR_UNSUPPORTED, "pa_comm_all_reduce: unsupported data type code: %d", dtype);
+  if (count == 0 || c->world == 1) return PA_OK;
+  PA_REQUIRE(c->connected, "pa_comm_all_reduce: communicator is not connected");
+  PA_REQUIRE(data != nullptr && aligned16(data), "pa_comm_all_reduce: data must be a 16-byte aligned device pointer");
+  const size_t bytes = count * (size_t)elem_size(dtype);
+  PA_REQUIRE(bytes % 16 == 0, "pa_comm_all_reduce: message of %zu bytes is not a multiple of 16", bytes);
+  PA_REQUIRE(bytes <= c->max_bytes, "pa_comm_all_reduce: message of %zu bytes exceeds the communicator's %zu", bytes,
+             c->max_bytes);
+  CommArgs a;
+  for (int p = 0; p < kCommMaxRanks; p++) {
+    a.ctrl[p] = p < c->world ? c->peer_ctrl[p] : nullptr;
+    a.inbox[p] = p < c->world ? c->peer_inbox[p] : nullptr;
+  }
+  a.data = data;
+  a.slot_bytes = c->slot_bytes;
+  a.n16 = bytes / 16;
+  a.rank = c->rank;
+  a.world = c->world;
+  // one vector per thread and pass; few workgroups (all resident at once, whatever else runs)
+  size_t wgs = (a.n16 + kCommThreads - 1) / kCommThreads;
+  if (wgs > (size_t)kCommMaxWorkgroups) wgs = kCommMaxWorkgroups;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case PA_DTYPE_F32:
+      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<float>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
+      break;
+    case PA_DTYPE_F16:
+      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<_Float16>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
+      break;
+    default:
+      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<__bf16>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
+      break;
+  }
+  PA_CHECK_LAUNCH("pa_comm_all_reduce_kernel launch");
+  return PA_OK;
+}
+
+extern "C" int pa_comm_status(pa_comm* c, uint32_t* reduces_done, uint32_t* timeouts) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(c != nullptr, "pa_comm_status: null communicator");
+  uint32_t words[kCtrlWords];
+  PA_COMM_HIP(hipMemcpy(words, c->ctrl, sizeof(words), hipMemcpyDeviceToHost), "pa_comm_status: hipMemcpy");
+  if (reduces_done != nullptr) *reduces_done = words[kSeq];
+  if (timeouts != nullptr) *timeouts = words[kTimeouts];
+  return PA_OK;
+}
+
+extern "C" int pa_comm_destroy(pa_comm* c) {
+  pa::clear_error();
+  return pa::comm_free(c);
+}
