@@ -605,6 +605,16 @@ def main(argv=None):
     workspace = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
 
     if args.roofline_only:
+        # Bring the GPU to its sustained clocks first, with a kernel of another name (so that a
+        # kernel trace of this command holds steady-state decode launches only): the full bench has
+        # its warm-up steps before the isolated launches, this mode would otherwise time the ramp.
+        ramp = torch.empty(1 << 28, dtype=torch.float16, device=device)
+        t_end = time.perf_counter() + 0.5
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                ramp.add_(1.0)
+            torch.cuda.synchronize()
+        del ramp
         roof = decode_roofline(torch, attention_ops, cache_ops, w, workspace, 40)
         if dist.rank == 0:
             print(json.dumps({"roofline": roof}))
