@@ -420,6 +420,20 @@ int pa_silu_and_mul(
  */
 #define PA_COMM_HANDLE_BYTES 128
 
+/*
+ * algorithm: PA_COMM_ONE_SHOT as described above (the whole message to every
+ * peer, one round of flags); PA_COMM_TWO_SHOT: rank r owns the r-th part of
+ * the message — every rank pushes each peer the part that peer owns, the
+ * owners sum and push the sums to everybody, two rounds of flags, 2 / N of the
+ * message per link; PA_COMM_AUTO picks two-shot for more than two ranks once
+ * it saves at least 256 KiB per link.  All ranks must pass the same value.
+ */
+typedef enum pa_comm_algorithm {
+  PA_COMM_AUTO = 0,
+  PA_COMM_ONE_SHOT = 1,
+  PA_COMM_TWO_SHOT = 2
+} pa_comm_algorithm;
+
 typedef struct pa_comm pa_comm;
 
 int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** comm,
@@ -427,7 +441,7 @@ int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** comm,
 int pa_comm_connect(pa_comm* comm, const unsigned char* all_handles);
 int pa_comm_connect_local(pa_comm* comm, pa_comm* const* all_comms);
 int pa_comm_all_reduce(pa_comm* comm, void* data, size_t count, int dtype,
-                       void* stream);
+                       int algorithm, void* stream);
 int pa_comm_status(pa_comm* comm, uint32_t* reduces_done, uint32_t* timeouts);
 int pa_comm_destroy(pa_comm* comm);
 

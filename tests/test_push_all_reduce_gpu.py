@@ -12,6 +12,7 @@ import pytest
 from tests.test_all_reduce import _run_ranks
 
 pytestmark = pytest.mark.gpu
+_STREAMS = {}
 
 
 def _expected(parts, dtype):
@@ -27,14 +28,18 @@ def _bits(t):
     return t.view(torch.int16 if t.element_size() == 2 else torch.int32)
 
 
+@pytest.mark.parametrize("algorithm", ["one_shot", "two_shot"])
 @pytest.mark.parametrize("world", [2])
-def test_ranks_on_one_gpu_by_pointer(pkg, world):
+def test_ranks_on_one_gpu_by_pointer(pkg, world, algorithm):
     import torch
     from vllm_amd.worker import PushAllReduce
     dev = torch.device("cuda:0")
     max_bytes = 1 << 20
-    ranks = PushAllReduce.local_ranks(world, max_bytes)
-    streams = [torch.cuda.Stream(dev) for _ in range(world)]
+    ranks = PushAllReduce.local_ranks(world, max_bytes, algorithm={"one_shot": PushAllReduce.ONE_SHOT,
+                                                                   "two_shot": PushAllReduce.TWO_SHOT}[algorithm])
+    # the same streams for every case of this module: the first ones a process creates get hardware
+    # queues of their own, later ones share
+    streams = _STREAMS.setdefault(world, [torch.cuda.Stream(dev) for _ in range(world)])
     try:
         g = torch.Generator(device="cpu").manual_seed(world)
         k = 0
@@ -79,15 +84,24 @@ _IPC_WORKER = textwrap.dedent("""
     torch.cuda.set_device(0)                       # every rank on the one card
     dev = torch.device("cuda:0")
     tokens, hidden = 64, 512
-    reduce = PushAllReduce(tokens * hidden * 2)
+    reduce = PushAllReduce(1024 * hidden * 2)
     g = torch.Generator(device="cpu").manual_seed(11)
-    for step, n in enumerate((64, 8, 64, 24)):
-        parts = [torch.randn(n, hidden, generator=g).half() for _ in range(world)]   # same on every rank
-        want = sum((p.float() for p in parts[1:]), parts[0].float()).half()
-        x = parts[rank].to(dev)
-        reduce(x)
-        torch.cuda.synchronize()
-        assert torch.equal(x.cpu().view(torch.int16), want.view(torch.int16)), (rank, step)
+    bare = 0
+    # both forms, switched between reduces of one communicator; 1024 x 512 fp16 = 1 MiB is where
+    # AUTO takes the two-shot form with four and eight ranks
+    for algorithm in (PushAllReduce.ONE_SHOT, PushAllReduce.TWO_SHOT, PushAllReduce.AUTO, PushAllReduce.TWO_SHOT,
+                      PushAllReduce.ONE_SHOT):
+        reduce.algorithm = algorithm
+        for n, dtype in ((64, torch.float16), (1024, torch.bfloat16), (8, torch.float16), (3, torch.float32),
+                         (1000, torch.float16)):
+            parts = [torch.randn(n, hidden, generator=g).to(dtype) for _ in range(world)]   # same on every rank
+            want = sum((p.float() for p in parts[1:]), parts[0].float()).to(dtype)
+            x = parts[rank].to(dev)
+            reduce(x)
+            torch.cuda.synchronize()
+            bare += 1
+            assert torch.equal(x.cpu().view(torch.int32), want.view(torch.int32)), (rank, algorithm, n, dtype)
+    reduce.algorithm = PushAllReduce.AUTO
     # inside the launcher, as the tensor-parallel step uses it: side stream, events, one HIP graph per
     # (buffer, token count) captured on first use with live partial sums, replayed with fresh ones
     launcher = GraphAllReduce(tokens, hidden, torch.float16, device=dev, reduce_fn=reduce)
@@ -105,7 +119,7 @@ _IPC_WORKER = textwrap.dedent("""
     # 16 and 40 tokens met buffer 0 of the ring, 64 buffer 1: three graphs, each captured after one warm-up reduce
     assert sorted(launcher.graphs) == [(0, 16), (0, 40), (1, 64)], sorted(launcher.graphs)
     done, timeouts = reduce.status()
-    assert (done, timeouts) == (4 + 7 + 3, 0), (rank, done, timeouts)
+    assert (done, timeouts) == (bare + 7 + 3, 0), (rank, done, timeouts)
     dist.barrier()
     reduce.close()
     print(f"rank {rank} ok", flush=True)

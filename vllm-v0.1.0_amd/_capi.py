@@ -112,7 +112,7 @@ def _load() -> ctypes.CDLL:
     lib.pa_comm_connect.restype = i32
     lib.pa_comm_connect_local.argtypes = [vp, ctypes.POINTER(vp)]
     lib.pa_comm_connect_local.restype = i32
-    lib.pa_comm_all_reduce.argtypes = [vp, vp, ctypes.c_size_t, i32, vp]
+    lib.pa_comm_all_reduce.argtypes = [vp, vp, ctypes.c_size_t, i32, i32, vp]
     lib.pa_comm_all_reduce.restype = i32
     lib.pa_comm_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     lib.pa_comm_status.restype = i32
@@ -351,9 +351,13 @@ def comm_connect_local(comm, all_comms) -> None:
     check(lib.pa_comm_connect_local(comm, arr))
 
 
-def comm_all_reduce(comm, tensor, stream=None) -> None:
+COMM_AUTO, COMM_ONE_SHOT, COMM_TWO_SHOT = 0, 1, 2
+
+
+def comm_all_reduce(comm, tensor, stream=None, algorithm: int = COMM_AUTO) -> None:
     """In-place sum of a contiguous tensor over the communicator's ranks, on `stream` (default: torch's current)."""
-    check(lib.pa_comm_all_reduce(comm, tensor.data_ptr(), tensor.numel(), dtype_code(tensor.dtype), _stream_handle(stream)))
+    check(lib.pa_comm_all_reduce(comm, tensor.data_ptr(), tensor.numel(), dtype_code(tensor.dtype), int(algorithm),
+                                 _stream_handle(stream)))
 
 
 def comm_status(comm):

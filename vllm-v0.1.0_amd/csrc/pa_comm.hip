@@ -1,4 +1,4 @@
-// One-shot all-reduce for the small messages of tensor parallelism on MI355X (gfx950).
+// One-shot and two-shot all-reduce for the small messages of tensor parallelism on MI355X (gfx950).
 //
 // The reference sums the partial results of every row-parallel matmul over the tensor-parallel
 // group with NCCL's all-reduce replayed from a CUDA graph
@@ -29,6 +29,13 @@
 //
 // The sequence number lives in device memory, not in the kernel arguments, so a captured launch
 // can be replayed from a HIP graph.
+//
+// Two-shot form, for messages big enough that link time outweighs a second barrier: rank r owns
+// the r-th N-th of the message.  Every rank pushes each peer ITS chunk only, the owners sum
+// their chunks (rank order, fp32) and push the sums back out, a second round of flags, and
+// everybody copies the N - 1 foreign chunks home: 2 / N of the message per link instead of all
+// of it.  Same inboxes (first half of a slot: the contribution, second half: the owner's sum),
+// same parity argument, a second flag array.
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -42,9 +49,15 @@ constexpr int kCommMaxRanks = 8;
 constexpr int kCommThreads = 256;
 constexpr int kCommMaxWorkgroups = 128;
 constexpr unsigned long long kWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr size_t kTwoShotSavedBytes = 256 * 1024;         // see pa_comm_all_reduce
 
 // control words of a rank, in uncached device memory
-enum : int { kFlag0 = 0, kSeq = kCommMaxRanks, kArrived, kFinished, kTimeouts, kCtrlWords = 16 };
+enum : int {
+  kFlag0 = 0,                     // [8] contributions delivered (both forms)
+  kFlagB0 = kCommMaxRanks,        // [8] owners' sums delivered (two-shot form)
+  kSeq = 2 * kCommMaxRanks, kArrived, kArrivedB, kFinished, kTimeouts,
+  kCtrlWords = 32
+};
 
 struct CommArgs {
   uint32_t* ctrl[kCommMaxRanks];  // every rank's control words, as mapped here
@@ -107,44 +120,31 @@ template <> struct Acc<__bf16> {
   }
 };
 
-template <typename T>
-__global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const CommArgs a) {
-  __shared__ int last_to_arrive;
+// The workgroup counts itself as arrived (every wave has released its stores); the last one to
+// arrive raises this rank's flag `flag0 + rank` = k in every peer's control words.
+__device__ __forceinline__ void arrive_and_signal(const CommArgs& a, uint32_t* ctrl, int counter, int flag0, uint32_t k,
+                                                  int* last_to_arrive) {
   const int tid = threadIdx.x;
-  uint32_t* ctrl = a.ctrl[a.rank];
-  // written by the last workgroup of the previous reduce (or zero): stable for this whole launch
-  const uint32_t k = __hip_atomic_load(&ctrl[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-  const size_t parity_off = (size_t)(k & 1u) * a.world * a.slot_bytes;
-  u32x4* data = static_cast<u32x4*>(a.data);
-  const size_t stride = (size_t)gridDim.x * kCommThreads;
-
-  // 1. push this rank's contribution into slot `rank` of every peer's inbox
-  for (size_t i = (size_t)blockIdx.x * kCommThreads + tid; i < a.n16; i += stride) {
-    const u32x4 v = data[i];
-    for (int p = 0; p < a.world; p++) {
-      if (p == a.rank) continue;
-      *reinterpret_cast<u32x4*>(a.inbox[p] + parity_off + (size_t)a.rank * a.slot_bytes + i * 16) = v;
-    }
-  }
-  // every wave: its stores have reached the peers before the workgroup counts as arrived
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // every wave: its stores have reached the peers
   __syncthreads();
   if (tid == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(&ctrl[kArrived], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    last_to_arrive = before + 1u == gridDim.x;
+    const uint32_t before = __hip_atomic_fetch_add(&ctrl[counter], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    *last_to_arrive = before + 1u == gridDim.x;
   }
   __syncthreads();
-  if (last_to_arrive) {
-    // the whole contribution is out: tell every peer
+  if (*last_to_arrive) {
     if (tid < a.world && tid != a.rank)
-      __hip_atomic_store(&a.ctrl[tid][kFlag0 + a.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) __hip_atomic_store(&ctrl[kArrived], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.ctrl[tid][flag0 + a.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(&ctrl[counter], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
 
-  // 2. wait for every peer's contribution to this reduce (or a later one: flags only grow)
+// Waits until every peer's flag `flag0 + peer` here has reached k (flags only grow), or gives up.
+__device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl, int flag0, uint32_t k) {
+  const int tid = threadIdx.x;
   if (tid < a.world && tid != a.rank) {
     const unsigned long long t0 = wall_clock64();
-    while ((int32_t)(__hip_atomic_load(&ctrl[kFlag0 + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+    while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
       if (wall_clock64() - t0 > kWaitTicks) {
         __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -154,29 +154,94 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every wave: nothing read below comes from a stale cache line
+}
 
-  // 3. sum the contributions in rank order, in place over this rank's own
-  const char* mine = a.inbox[a.rank] + parity_off;
-  for (size_t i = (size_t)blockIdx.x * kCommThreads + tid; i < a.n16; i += stride) {
-    float acc[Acc<T>::N];
-#pragma unroll
-    for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
-    for (int p = 0; p < a.world; p++) {
-      const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + i * 16);
-      Acc<T>::add(acc, v);
-    }
-    data[i] = Acc<T>::pack(acc);
-  }
-
-  // 4. the last workgroup to finish closes the reduce
+// The last workgroup to finish closes the reduce.
+__device__ __forceinline__ void finish(uint32_t* ctrl, uint32_t k) {
   __syncthreads();
-  if (tid == 0) {
+  if (threadIdx.x == 0) {
     const uint32_t before = __hip_atomic_fetch_add(&ctrl[kFinished], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (before + 1u == gridDim.x) {
       __hip_atomic_store(&ctrl[kFinished], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&ctrl[kSeq], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+template <typename T, bool TWO_SHOT>
+__global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const CommArgs a) {
+  __shared__ int last_to_arrive;
+  const int tid = threadIdx.x;
+  uint32_t* ctrl = a.ctrl[a.rank];
+  // written by the last workgroup of the previous reduce (or zero): stable for this whole launch
+  const uint32_t k = __hip_atomic_load(&ctrl[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const size_t parity_off = (size_t)(k & 1u) * a.world * a.slot_bytes;
+  u32x4* data = static_cast<u32x4*>(a.data);
+  const size_t first = (size_t)blockIdx.x * kCommThreads + tid;
+  const size_t stride = (size_t)gridDim.x * kCommThreads;
+  const char* mine = a.inbox[a.rank] + parity_off;
+  const size_t my_slot = parity_off + (size_t)a.rank * a.slot_bytes;  // where this rank writes in a peer's inbox
+
+  if (!TWO_SHOT) {
+    // 1. push this rank's contribution into slot `rank` of every peer's inbox
+    for (size_t i = first; i < a.n16; i += stride) {
+      const u32x4 v = data[i];
+      for (int p = 0; p < a.world; p++) {
+        if (p == a.rank) continue;
+        *reinterpret_cast<u32x4*>(a.inbox[p] + my_slot + i * 16) = v;
+      }
+    }
+    arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
+    // 2. wait for every peer's contribution to this reduce
+    wait_for_peers(a, ctrl, kFlag0, k);
+    // 3. sum the contributions in rank order, in place over this rank's own
+    for (size_t i = first; i < a.n16; i += stride) {
+      float acc[Acc<T>::N];
+#pragma unroll
+      for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
+      for (int p = 0; p < a.world; p++) {
+        const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + i * 16);
+        Acc<T>::add(acc, v);
+      }
+      data[i] = Acc<T>::pack(acc);
+    }
+  } else {
+    // rank c owns vectors [c * q, (c + 1) * q) of the message
+    const size_t q = (a.n16 + a.world - 1) / a.world;
+    // 1. push every peer the part of this rank's contribution that the peer owns
+    for (size_t i = first; i < a.n16; i += stride) {
+      const int c = (int)(i / q);
+      if (c != a.rank) *reinterpret_cast<u32x4*>(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16) = data[i];
+    }
+    arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
+    wait_for_peers(a, ctrl, kFlag0, k);
+    // 2. sum the chunk this rank owns, in rank order; keep it and push it to every peer
+    const size_t lo = (size_t)a.rank * q, hi = lo + q < a.n16 ? lo + q : a.n16;
+    for (size_t i = lo + first; i < hi; i += stride) {
+      float acc[Acc<T>::N];
+#pragma unroll
+      for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
+      for (int p = 0; p < a.world; p++) {
+        const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + (i - lo) * 16);
+        Acc<T>::add(acc, v);
+      }
+      const u32x4 r = Acc<T>::pack(acc);
+      data[i] = r;
+      for (int p = 0; p < a.world; p++) {
+        if (p == a.rank) continue;
+        *reinterpret_cast<u32x4*>(a.inbox[p] + my_slot + (q + (i - lo)) * 16) = r;
+      }
+    }
+    arrive_and_signal(a, ctrl, kArrivedB, kFlagB0, k, &last_to_arrive);
+    wait_for_peers(a, ctrl, kFlagB0, k);
+    // 3. bring the other owners' sums home
+    for (size_t i = first; i < a.n16; i += stride) {
+      const int c = (int)(i / q);
+      if (c != a.rank)
+        data[i] = *reinterpret_cast<const u32x4*>(mine + (size_t)c * a.slot_bytes + (q + (i - (size_t)c * q)) * 16);
+    }
+  }
+  finish(ctrl, k);
 }
 
 }  // namespace pa
@@ -232,7 +297,7 @@ extern "C" int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** c
   c->rank = rank;
   c->world = world;
   c->max_bytes = max_bytes;
-  c->slot_bytes = (max_bytes + 255) / 256 * 256;
+  c->slot_bytes = (max_bytes + 255) / 256 * 256 + 256;  // the two-shot form rounds its chunks up
   memset(handles_out, 0, PA_COMM_HANDLE_BYTES);
   hipError_t e = hipGetDevice(&c->device);
   if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->ctrl), 256, hipDeviceMallocUncached);
@@ -240,9 +305,10 @@ extern "C" int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** c
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->inbox), 2 * (size_t)world * c->slot_bytes);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
+    const size_t inbox_bytes = 2 * (size_t)world * c->slot_bytes;
     comm_free(c);
-    return fail(PA_ERR_HIP, "pa_comm_create: allocating the control words and a %zu-byte inbox: %s",
-                2 * (size_t)world * ((max_bytes + 255) / 256 * 256), hipGetErrorString(e));
+    return fail(PA_ERR_HIP, "pa_comm_create: allocating the control words and a %zu-byte inbox: %s", inbox_bytes,
+                hipGetErrorString(e));
   }
   // Handles for peers in other processes.  A communicator whose peers live in this process
   // (pa_comm_connect_local) never needs them: failing to export is not an error here.
@@ -307,7 +373,7 @@ extern "C" int pa_comm_connect_local(pa_comm* c, pa_comm* const* all) {
   return PA_OK;
 }
 
-extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtype, void* stream) {
+extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtype, int algorithm, void* stream) {
   using namespace pa;
   clear_error();
   PA_REQUIRE(c != nullptr, "pa_comm_all_reduce: null communicator");
@@ -330,21 +396,30 @@ extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtyp
   a.n16 = bytes / 16;
   a.rank = c->rank;
   a.world = c->world;
+  PA_REQUIRE(algorithm == PA_COMM_AUTO || algorithm == PA_COMM_ONE_SHOT || algorithm == PA_COMM_TWO_SHOT,
+             "pa_comm_all_reduce: unknown algorithm code %d", algorithm);
+  // Two-shot when the link time it saves (a fraction (N - 2) / N of the message) outweighs its
+  // second round of flags: from kTwoShotSavedBytes saved per link on.  Every rank decides alike.
+  bool two_shot = algorithm == PA_COMM_TWO_SHOT;
+  if (algorithm == PA_COMM_AUTO) two_shot = c->world > 2 && bytes / c->world * (c->world - 2) >= kTwoShotSavedBytes;
+  if (c->world == 2 && algorithm == PA_COMM_AUTO) two_shot = false;
   // one vector per thread and pass; few workgroups (all resident at once, whatever else runs)
   size_t wgs = (a.n16 + kCommThreads - 1) / kCommThreads;
   if (wgs > (size_t)kCommMaxWorkgroups) wgs = kCommMaxWorkgroups;
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define PA_COMM_LAUNCH(T)                                                                                          \
+  do {                                                                                                             \
+    if (two_shot)                                                                                                  \
+      hipLaunchKernelGGL((pa_comm_all_reduce_kernel<T, true>), dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((pa_comm_all_reduce_kernel<T, false>), dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a); \
+  } while (0)
   switch (dtype) {
-    case PA_DTYPE_F32:
-      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<float>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
-      break;
-    case PA_DTYPE_F16:
-      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<_Float16>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
-      break;
-    default:
-      hipLaunchKernelGGL(pa_comm_all_reduce_kernel<__bf16>, dim3((unsigned)wgs), dim3(kCommThreads), 0, st, a);
-      break;
+    case PA_DTYPE_F32: PA_COMM_LAUNCH(float); break;
+    case PA_DTYPE_F16: PA_COMM_LAUNCH(_Float16); break;
+    default: PA_COMM_LAUNCH(__bf16); break;
   }
+#undef PA_COMM_LAUNCH
   PA_CHECK_LAUNCH("pa_comm_all_reduce_kernel launch");
   return PA_OK;
 }

@@ -31,9 +31,15 @@ class PushAllReduce:
 
     MAX_RANKS = 8
 
+    AUTO, ONE_SHOT, TWO_SHOT = _capi.COMM_AUTO, _capi.COMM_ONE_SHOT, _capi.COMM_TWO_SHOT
+
     def __init__(self, max_bytes: int, group: Optional[dist.ProcessGroup] = None,
-                 device: Optional[torch.device] = None, _local=None) -> None:
+                 device: Optional[torch.device] = None, algorithm: int = _capi.COMM_AUTO, _local=None) -> None:
+        """algorithm: AUTO (by message size and group size), ONE_SHOT (the whole message to every peer,
+        one round of flags) or TWO_SHOT (each rank sums one N-th of it: 2 / N of the bytes per link, two
+        rounds of flags); the same on every rank."""
         self.max_bytes = int(max_bytes)
+        self.algorithm = int(algorithm)
         self._comm = None
         if _local is not None:  # (rank, world): connected later by local_ranks
             self.rank, self.world = _local
@@ -52,11 +58,12 @@ class PushAllReduce:
             dist.barrier(group=group)  # no rank reduces before every rank has mapped every inbox
 
     @classmethod
-    def local_ranks(cls, world: int, max_bytes: int, devices: Optional[Sequence[torch.device]] = None) -> List["PushAllReduce"]:
+    def local_ranks(cls, world: int, max_bytes: int, devices: Optional[Sequence[torch.device]] = None,
+                    algorithm: int = _capi.COMM_AUTO) -> List["PushAllReduce"]:
         """All ranks of a group inside this process, connected by pointer.  devices: one per rank
         (default: the current device for every rank)."""
         devices = list(devices) if devices is not None else [torch.device("cuda", torch.cuda.current_device())] * world
-        ranks = [cls(max_bytes, device=devices[r], _local=(r, world)) for r in range(world)]
+        ranks = [cls(max_bytes, device=devices[r], algorithm=algorithm, _local=(r, world)) for r in range(world)]
         for r in ranks:
             with torch.cuda.device(r.device):
                 _capi.comm_connect_local(r._comm, [x._comm for x in ranks])
@@ -68,7 +75,7 @@ class PushAllReduce:
             raise ValueError("the one-shot all-reduce takes a contiguous tensor")
         if t.device != self.device:
             raise ValueError(f"tensor on {t.device}, communicator on {self.device}")
-        _capi.comm_all_reduce(self._comm, t, torch.cuda.current_stream(self.device))
+        _capi.comm_all_reduce(self._comm, t, torch.cuda.current_stream(self.device), self.algorithm)
 
     def status(self):
         """(reduces completed, waits given up); synchronises with the device."""
