@@ -132,3 +132,25 @@ def test_ranks_in_processes_of_their_own_through_ipc(pkg, world):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     for r in range(world):
         assert f"rank {r} ok" in res.stdout
+
+
+def test_bench_head_sharded_step_with_the_push_collective_two_ranks_on_one_gpu(pkg):
+    """bench.py --tp as the driver launches it (torch.distributed.run, one line from rank 0), with both ranks
+    on the one card: rendezvous over gloo, the all-reduce through the inboxes, replayed from HIP graphs."""
+    import json
+    import subprocess
+    import sys
+    from tests.test_all_reduce import ROOT, _free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--tp", "--steps", "2",
+           "--warmup", "1", "--layers", "2", "--batch", "32", "--ctx", "256", "--dist-backend", "gloo",
+           "--tp-collective", "push", "--tp-graph", "--no-c2", "--no-cpu-baseline", "--no-roofline"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["tp"]["tp"] == 2 and "push" in d["tp"]["all_reduce_collective"]
+    assert d["tp"]["push_waits_given_up"] == 0 and d["tp"]["push_reduces_done"] > 0
