@@ -40,6 +40,13 @@ SHAPES = {
     "share3_ns": dict(S=255, H=32, D=128, B=16, ctx=1024, ragged=False, share=3),
     "ragged2048": dict(S=256, H=32, D=128, B=16, ctx=2048, ragged=True),
     "ragged4096_bs128": dict(S=128, H=32, D=128, B=16, ctx=4096, ragged=True),
+    # long-tailed lengths, like a chat corpus
+    "lognormal": dict(S=256, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
+    "lognormal_bs128": dict(S=128, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
+    "lognormal_bs64": dict(S=64, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
+    "short256": dict(S=256, H=32, D=128, B=16, ctx=256, ragged=False),
+    "bs64": dict(S=64, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs128": dict(S=128, H=32, D=128, B=16, ctx=1024, ragged=False),
 }
 
 
@@ -79,6 +86,10 @@ def main():
         g = torch.Generator(device="cpu")
         g.manual_seed(0)
         ctxs = torch.randint(1, ctx + 1, (S,), generator=g).tolist() if c["ragged"] else [ctx] * S
+        if c["ragged"] == "lognormal":
+            import math
+            import numpy as np
+            ctxs = [int(min(max(v, 1), ctx)) for v in np.random.default_rng(0).lognormal(math.log(300.0), 1.0, S)]
         bps = (ctx + B - 1) // B
         share = c.get("share", 1)
         groups = (S + share - 1) // share
