@@ -47,7 +47,7 @@ def test_single_process_plumbing():
 def test_algorithmic_bytes_match_the_baseline_table():
     sys.path.insert(0, ROOT)
     import bench
-    # BASELINE.md section 3
+    # per launch: K and V of every token once, plus q, out, the block tables and context lengths
     assert bench.algorithmic_bytes([1024] * 256, 12, 64, 16, 2) == 806_159_360
     assert bench.algorithmic_bytes([1024] * 256, 32, 128, 16, 2) == 4_299_228_160
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Whole LLaMA-shaped decode step around the path: what BASELINE's
-"output tokens/s, LLaMA-7B TP=1, batch 256" looks like when the GEMMs (torch /
+"""Whole LLaMA-shaped decode step around the path: what "output tokens/s,
+LLaMA-7B TP=1, batch 256" looks like when the GEMMs (torch /
 hipBLASLt), sampler (argmax) and embedding run too.  Random weights of the
 architecture's shapes, batch 256, every sequence at context 1024, caches of
 all layers resident.  The operators between the GEMMs are this package's:

@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# The commands behind the numbers in DESIGN.md, for a box with one MI355X.
+# The commands behind the measured numbers of this repository, for a box with one MI355X.
 # Each writes its output under gpurun_out/; the copies kept in profiles/ were
 # made from those files.
 set -euo pipefail
