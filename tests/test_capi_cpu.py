@@ -109,3 +109,26 @@ def test_operator_modules_reject_cpu_tensors_and_bad_shapes(pkg):
     pkg.cache_ops.copy_blocks([], [], {0: [1]})
     with pytest.raises(RuntimeError, match="must be on the GPU"):
         pkg.cache_ops.copy_blocks([kc], [vc], {0: [1]})
+
+
+def test_communicator_and_append_entry_validate_arguments_without_a_gpu(pkg):
+    c = pkg._capi
+    lib = c.lib
+    comm = ctypes.c_void_p()
+    blob = (ctypes.c_ubyte * c.COMM_HANDLE_BYTES)()
+    assert lib.pa_comm_create(3, 2, 1024, ctypes.byref(comm), blob) == c.PA_ERR_INVALID_ARGUMENT
+    assert "rank 3 of 2" in c.last_error()
+    assert lib.pa_comm_create(0, 9, 1024, ctypes.byref(comm), blob) == c.PA_ERR_INVALID_ARGUMENT
+    assert lib.pa_comm_create(0, 2, 0, ctypes.byref(comm), blob) == c.PA_ERR_INVALID_ARGUMENT
+    assert "max_bytes" in c.last_error()
+    assert lib.pa_comm_all_reduce(None, None, 8, c.PA_DTYPE_F16, 0, None) == c.PA_ERR_INVALID_ARGUMENT
+    assert lib.pa_comm_connect(None, None) == c.PA_ERR_INVALID_ARGUMENT
+    assert lib.pa_comm_destroy(None) == c.PA_OK
+    one = ctypes.c_void_p(16)
+    # the new token rows must be at least num_heads x head_size elements apart
+    rc = lib.pa_append_single_query_cached_kv_attention(
+        one, one, one, one, one, one, 1.0, one, one, 2, 2, 64, 16, 1, 16, 128, 64, 128, c.PA_DTYPE_F16, None, 0, 0, -1, None)
+    assert rc == c.PA_ERR_INVALID_ARGUMENT and "shorter than a token row" in c.last_error()
+    rc = lib.pa_append_single_query_cached_kv_attention(
+        one, one, None, one, one, one, 1.0, one, one, 2, 2, 64, 16, 1, 16, 128, 128, 128, c.PA_DTYPE_F16, None, 0, 0, -1, None)
+    assert rc == c.PA_ERR_INVALID_ARGUMENT and "null key / value" in c.last_error()
