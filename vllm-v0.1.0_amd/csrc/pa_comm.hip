@@ -20,10 +20,15 @@
 // contributions in rank order in fp32, so all ranks hold bit-identical sums.
 //
 // Memory: peers' inboxes and flag words are reached through IPC mappings (one process per GPU)
-// or plain pointers (several communicators in one process).  Flags live in uncached memory and
-// are written / read with system-scope release / acquire; the data stores are ordinary vector
-// stores made visible by the release fence every wave executes before the workgroup counts
-// itself as arrived.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
+// or plain pointers (several communicators in one process).  Nothing here uses a release or
+// acquire FENCE: on this chip a fence at agent or system scope writes back or invalidates a
+// whole L2, which stalls every other kernel on the GPU (measured in the decode kernel: a few
+// hundred workgroups fencing once each made a 170 us launch take 1.7 ms) — and the all-reduce
+// is meant to run beside the attention kernels.  Instead every access to memory that another
+// rank writes or reads is itself a relaxed system-scope atomic (8-byte stores that write
+// through to the destination, 8-byte loads that pass the caches), a wave waits for its stores
+// to be acknowledged (s_waitcnt vmcnt(0)) before its workgroup counts as arrived, and the
+// flags are relaxed system-scope atomics in uncached memory.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
 // peers never arrive gives up, counts a timeout that pa_comm_status reports, and finishes the
 // launch with a meaningless result rather than hanging the GPU.
 //
@@ -120,21 +125,35 @@ template <> struct Acc<__bf16> {
   }
 };
 
+// 16 bytes to / from memory shared with other ranks: two relaxed system-scope atomics each, i.e.
+// write-through stores and cache-bypassing loads (see the note on fences above).
+__device__ __forceinline__ void store_shared(char* p, u32x4 v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(q + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ u32x4 load_shared(const char* p) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<char*>(p));
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+}
+
 // The workgroup counts itself as arrived (every wave has released its stores); the last one to
 // arrive raises this rank's flag `flag0 + rank` = k in every peer's control words.
 __device__ __forceinline__ void arrive_and_signal(const CommArgs& a, uint32_t* ctrl, int counter, int flag0, uint32_t k,
                                                   int* last_to_arrive) {
   const int tid = threadIdx.x;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // every wave: its stores have reached the peers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have been acknowledged
   __syncthreads();
   if (tid == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(&ctrl[counter], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t before = __hip_atomic_fetch_add(&ctrl[counter], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *last_to_arrive = before + 1u == gridDim.x;
   }
   __syncthreads();
   if (*last_to_arrive) {
     if (tid < a.world && tid != a.rank)
-      __hip_atomic_store(&a.ctrl[tid][flag0 + a.rank], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&a.ctrl[tid][flag0 + a.rank], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) __hip_atomic_store(&ctrl[counter], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -144,7 +163,7 @@ __device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl
   const int tid = threadIdx.x;
   if (tid < a.world && tid != a.rank) {
     const unsigned long long t0 = wall_clock64();
-    while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
+    while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
       if (wall_clock64() - t0 > kWaitTicks) {
         __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -152,18 +171,17 @@ __device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // every wave: nothing read below comes from a stale cache line
+  __syncthreads();  // what the peers delivered is read with cache-bypassing loads from here on
 }
 
 // The last workgroup to finish closes the reduce.
 __device__ __forceinline__ void finish(uint32_t* ctrl, uint32_t k) {
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(&ctrl[kFinished], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t before = __hip_atomic_fetch_add(&ctrl[kFinished], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (before + 1u == gridDim.x) {
       __hip_atomic_store(&ctrl[kFinished], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&ctrl[kSeq], k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&ctrl[kSeq], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -188,7 +206,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
       const u32x4 v = data[i];
       for (int p = 0; p < a.world; p++) {
         if (p == a.rank) continue;
-        *reinterpret_cast<u32x4*>(a.inbox[p] + my_slot + i * 16) = v;
+        store_shared(a.inbox[p] + my_slot + i * 16, v);
       }
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
 #pragma unroll
       for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
       for (int p = 0; p < a.world; p++) {
-        const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + i * 16);
+        const u32x4 v = p == a.rank ? data[i] : load_shared(mine + (size_t)p * a.slot_bytes + i * 16);
         Acc<T>::add(acc, v);
       }
       data[i] = Acc<T>::pack(acc);
@@ -211,7 +229,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     // 1. push every peer the part of this rank's contribution that the peer owns
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
-      if (c != a.rank) *reinterpret_cast<u32x4*>(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16) = data[i];
+      if (c != a.rank) store_shared(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16, data[i]);
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
     wait_for_peers(a, ctrl, kFlag0, k);
@@ -222,14 +240,14 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
 #pragma unroll
       for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
       for (int p = 0; p < a.world; p++) {
-        const u32x4 v = p == a.rank ? data[i] : *reinterpret_cast<const u32x4*>(mine + (size_t)p * a.slot_bytes + (i - lo) * 16);
+        const u32x4 v = p == a.rank ? data[i] : load_shared(mine + (size_t)p * a.slot_bytes + (i - lo) * 16);
         Acc<T>::add(acc, v);
       }
       const u32x4 r = Acc<T>::pack(acc);
       data[i] = r;
       for (int p = 0; p < a.world; p++) {
         if (p == a.rank) continue;
-        *reinterpret_cast<u32x4*>(a.inbox[p] + my_slot + (q + (i - lo)) * 16) = r;
+        store_shared(a.inbox[p] + my_slot + (q + (i - lo)) * 16, r);
       }
     }
     arrive_and_signal(a, ctrl, kArrivedB, kFlagB0, k, &last_to_arrive);
@@ -238,7 +256,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
       if (c != a.rank)
-        data[i] = *reinterpret_cast<const u32x4*>(mine + (size_t)c * a.slot_bytes + (q + (i - (size_t)c * q)) * 16);
+        data[i] = load_shared(mine + (size_t)c * a.slot_bytes + (q + (i - (size_t)c * q)) * 16);
     }
   }
   finish(ctrl, k);
