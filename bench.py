@@ -356,7 +356,7 @@ def decode_roofline(torch, attention_ops, cache_ops, w, workspace, n_launch):
     }
 
 
-def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=None, emulate=0):
+def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=None, emulate=0, collective=None):
     """The head-sharded step: per layer reshape_and_cache + attention on this rank's heads, the
     row-parallel o_proj matmul into the launcher's ring buffer, the all-reduce on the side stream.
     Returns (elapsed seconds MAX over ranks, info dict)."""
@@ -390,9 +390,10 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         remote = torch.zeros(S, hidden, dtype=tdtype, device=device)
         reduce_fn = lambda t: t.add_(remote[:t.shape[0]])  # noqa: E731  (stand-in: same bytes, no xGMI)
     push = None
-    if not emulate and args.tp_collective == "push" and tp > 1:
+    if not emulate and (collective or args.tp_collective) == "push" and tp > 1:
         from vllm_amd.worker import PushAllReduce
         push = PushAllReduce(S * hidden * w.es, device=device)  # handles exchanged over the process group
+        push.self_test()  # all ranks agree that the peers' memory is reachable, or all raise
         reduce_fn = push
     elif not emulate and args.dist_backend != "nccl":
         # rehearsal on a box without one GPU per rank: the sum goes through host memory (the
@@ -677,6 +678,15 @@ def main(argv=None):
             extra["tp"] = info
         except Exception as e:  # noqa: BLE001
             extra["tp"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        if args.tp_collective != "push":
+            # the same step with this package's own all-reduce over peer-mapped inboxes
+            progress(dist, "head-sharded leg, one-shot push all-reduce")
+            try:
+                _, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w,
+                                    collective="push")
+                extra["tp_push"] = info
+            except Exception as e:  # noqa: BLE001
+                extra["tp_push"] = {"error": f"{type(e).__name__}: {e}"[:500]}
 
     # ---- CPU baseline --------------------------------------------------------------------------------
     if not args.no_cpu_baseline and dist.rank == 0 and dist.world == 1:

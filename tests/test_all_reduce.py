@@ -296,3 +296,34 @@ def test_graph_replay_over_rccl_two_ranks():
     res = _run_ranks(_RCCL_WORKER, 2, env_extra={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     assert "RCCL_GRAPH_OK" in res.stdout
+
+
+_PUSH_SETUP_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.getcwd())
+    import torch, torch.distributed as dist
+    import __graft_entry__
+    __graft_entry__.load_package()
+    from vllm_amd.worker import PushAllReduce
+    dist.init_process_group(backend="gloo")
+    rank = dist.get_rank()
+    # no GPU here: creating the communicator fails, and it must fail on every rank together
+    try:
+        PushAllReduce(1 << 16, device=torch.device("cuda", 0))
+        raise SystemExit("set-up succeeded without a GPU")
+    except RuntimeError as e:
+        assert "set-up failed on rank 0" in str(e), str(e)
+    dist.barrier()    # the group is still in step
+    print(f"rank {rank} ok", flush=True)
+""")
+
+
+def test_push_all_reduce_set_up_fails_on_all_ranks_together():
+    """Without a GPU the communicator cannot be created; every rank learns so in the same collective and
+    raises, instead of one rank raising and the others waiting in the next collective."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: set-up would succeed")
+    res = _run_ranks(_PUSH_SETUP_WORKER, 2, timeout=120)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout

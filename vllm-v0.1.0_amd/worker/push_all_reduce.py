@@ -48,14 +48,58 @@ class PushAllReduce:
         if self.world > self.MAX_RANKS:
             raise ValueError(f"{self.world} ranks: the one-shot all-reduce is for at most {self.MAX_RANKS} GPUs of a node")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        with torch.cuda.device(self.device):
-            self._comm, self._handles = _capi.comm_create(self.rank, self.world, self.max_bytes)
-        if _local is None:
-            gathered: List[Optional[bytes]] = [None] * self.world
-            dist.all_gather_object(gathered, self._handles, group=group)
+        self._group = group
+        if _local is not None:
             with torch.cuda.device(self.device):
-                _capi.comm_connect(self._comm, gathered)
-            dist.barrier(group=group)  # no rank reduces before every rank has mapped every inbox
+                self._comm, self._handles = _capi.comm_create(self.rank, self.world, self.max_bytes)
+            return
+        # Set-up succeeds or fails on ALL ranks: a rank that raised alone would leave the others
+        # waiting in the next collective of the group.
+        error: Optional[str] = None
+        handles = b""
+        try:
+            with torch.cuda.device(self.device):
+                self._comm, handles = _capi.comm_create(self.rank, self.world, self.max_bytes)
+        except Exception as e:  # noqa: BLE001
+            error = f"{type(e).__name__}: {e}"
+        gathered: List[Optional[bytes]] = [None] * self.world
+        dist.all_gather_object(gathered, None if error else handles, group=group)
+        if error is None and all(h is not None for h in gathered):
+            try:
+                with torch.cuda.device(self.device):
+                    _capi.comm_connect(self._comm, gathered)
+            except Exception as e:  # noqa: BLE001
+                error = f"{type(e).__name__}: {e}"
+        elif error is None:
+            error = "another rank could not create its communicator"
+        self._agree(error, "set-up")  # also the barrier: no rank reduces before every rank has mapped every inbox
+
+    def _agree(self, error: Optional[str], what: str) -> None:
+        """Collective: raises on every rank if any rank reports an error."""
+        errors: List[Optional[str]] = [None] * self.world
+        dist.all_gather_object(errors, error, group=self._group)
+        failed = [(r, e) for r, e in enumerate(errors) if e]
+        if failed:
+            self.close()
+            raise RuntimeError(f"one-shot all-reduce {what} failed on rank {failed[0][0]}: {failed[0][1]}")
+
+    def self_test(self) -> None:
+        """Collective: one small reduce of known values on every rank's current stream, checked on every
+        rank (sum, no wait given up); raises on every rank if any rank saw a wrong result.  A few seconds at
+        most even when peers cannot be reached (the kernel's waits are bounded)."""
+        error: Optional[str] = None
+        try:
+            n = min(4096, self.max_bytes // 2 // 8 * 8)
+            x = torch.full((n,), float(self.rank + 1), dtype=torch.float16, device=self.device)
+            self(x)
+            torch.cuda.synchronize(self.device)
+            want = float(self.world * (self.world + 1) // 2)
+            gave_up = self.status()[1]
+            if gave_up or not bool((x == want).all()):
+                error = f"sum {float(x[0])} (expected {want}), waits given up {gave_up}"
+        except Exception as e:  # noqa: BLE001
+            error = f"{type(e).__name__}: {e}"
+        self._agree(error, "self-test")
 
     @classmethod
     def local_ranks(cls, world: int, max_bytes: int, devices: Optional[Sequence[torch.device]] = None,
