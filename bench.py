@@ -655,6 +655,17 @@ def main(argv=None):
         in_step = sorted(e0.elapsed_time(e1) for e0, e1 in evs2)
         roof["in_step_launch_ms_median"] = median(in_step)
         roof["in_step_achieved"] = roof["bytes_per_launch"] / (median(in_step) * 1e-3) / 1e9
+        # What this box's memory does for a plain device-to-device copy, next to the vendor peak:
+        # one layer's value cache over another's, read + written bytes counted.
+        if L >= 2:
+            src, dst = w.value_caches[L - 1], w.value_caches[L - 2]  # synthetic values either way
+
+            def copy(i):
+                dst.copy_(src)
+            ts = time_launches(torch, copy, 10, warmup=2)
+            nbytes = 2 * src.numel() * src.element_size()
+            roof["device_copy"] = {"unit": "GB/s", "achieved": nbytes / (median(ts) * 1e-3) / 1e9,
+                                   "bytes": nbytes, "what": "torch tensor copy on the device, read + written bytes"}
         extra["roofline"] = roof
 
     # ---- the microbenchmark shape of BASELINE.json configs[1], same measurement -----------------
