@@ -288,12 +288,14 @@ class Workload:
                       file=sys.stderr)
             L = L_fit
         self.L = L
+        # placed the way this package's CacheEngine places a layer's caches (the value cache
+        # KV_STAGGER_BYTES behind the end of the key cache; worker/cache_engine.py says why)
+        from vllm_amd.worker import carve_kv_cache, kv_slab_elements
         self.key_caches, self.value_caches = [], []
         for _ in range(L):
-            kc = torch.empty(NB, H, D // x, B, x, dtype=tdtype, device=device)
-            vc = torch.empty(NB, H, D, B, dtype=tdtype, device=device)
-            kc.normal_(0.0, 0.5)
-            vc.normal_(0.0, 0.5)
+            slab = torch.empty(kv_slab_elements(1, NB, (H, D, B), es), dtype=tdtype, device=device)
+            slab.normal_(0.0, 0.5)
+            kc, vc = carve_kv_cache(slab, 0, NB, (H, D // x, B, x), (H, D, B))
             self.key_caches.append(kc)
             self.value_caches.append(vc)
         self.qkv = torch.empty(S, 3, H, D, dtype=tdtype, device=device).normal_(0.0, 0.5)
