@@ -608,16 +608,22 @@ def main(argv=None):
     workspace = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=device)
 
     if args.roofline_only:
-        # Bring the GPU to its sustained clocks first, with a kernel of another name (so that a
-        # kernel trace of this command holds steady-state decode launches only): the full bench has
-        # its warm-up steps before the isolated launches, this mode would otherwise time the ramp.
-        ramp = torch.empty(1 << 28, dtype=torch.float16, device=device)
+        # Bring the GPU to the state the full bench measures in — half a second of the same
+        # launches over every layer's caches — before timing: the full bench has its warm-up and
+        # timed steps before the isolated launches; this mode's first launches would otherwise be
+        # timed during the clock ramp and the first sweep over 128 GiB (650 instead of 633 us).
+        # A kernel trace of this command then holds several hundred launches in the steady state
+        # and a few dozen before it: its per-dispatch median is the steady state's.
+        attention_ops.single_query_cached_kv_attention_planned(
+            w.out, w.query, w.key_caches[0], w.value_caches[0], w.scale, w.block_tables, w.context_lens, B, CTX,
+            workspace, False, w.total_ctx)
         t_end = time.perf_counter() + 0.5
         while time.perf_counter() < t_end:
-            for _ in range(20):
-                ramp.add_(1.0)
+            for l in range(L):
+                attention_ops.single_query_cached_kv_attention_planned(
+                    w.out, w.query, w.key_caches[l], w.value_caches[l], w.scale, w.block_tables, w.context_lens, B, CTX,
+                    workspace, True, w.total_ctx)
             torch.cuda.synchronize()
-        del ramp
         roof = decode_roofline(torch, attention_ops, cache_ops, w, workspace, 40)
         if dist.rank == 0:
             print(json.dumps({"roofline": roof}))
