@@ -470,6 +470,15 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         if not emulate:
             info["all_reduce_isolated_us_max_over_ranks"] = dist.max_float(median(ts) * 1e3, device)
     if push is not None:
+        # both forms of the collective alone, for the message of this step: the data PA_COMM_AUTO's threshold needs
+        for name, algo in (("one_shot", push.ONE_SHOT), ("two_shot", push.TWO_SHOT)):
+            push.algorithm = algo
+            if use_graph:
+                launcher.graphs.clear()  # captured with the other form
+                launcher.precapture([S])
+            ts = time_launches(torch, one, 40, warmup=5)
+            info[f"all_reduce_isolated_us_{name}"] = dist.max_float(median(ts) * 1e3, device)
+        push.algorithm = push.AUTO
         done, gave_up = push.status()
         info["push_reduces_done"], info["push_waits_given_up"] = done, gave_up
         dist.barrier()
