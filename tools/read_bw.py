@@ -31,3 +31,18 @@ for nt in (0, 1):
             b.record(); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 10
             print(f"nt={nt} unroll={unroll:2d} grid={grid:6d}: {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:8.1f} GB/s", flush=True)
+
+# the loads' cache-policy bits written out (unroll 8)
+lib.read_bw_policy_launch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+for policy, name in enumerate(("sc0", "sc1", "sc0 sc1", "nt sc0", "nt sc1", "nt sc0 sc1")):
+    for grid in (8192, 32768):
+        def call():
+            assert lib.read_bw_policy_launch(buf.data_ptr(), nbytes, out.data_ptr(), grid, policy, st) == 0
+        for _ in range(3): call()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(10): call()
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / 10
+        print(f"policy {name:10s} unroll= 8 grid={grid:6d}: {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:8.1f} GB/s", flush=True)
