@@ -72,6 +72,37 @@ def test_ranks_on_one_gpu_by_pointer(pkg, world, algorithm):
             r.close()
 
 
+def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
+    """Rank 1 of two never launches: rank 0's first reduce gives up after the two-second bound and
+    counts it, and every later reduce of that communicator returns without waiting at all."""
+    import time
+    import torch
+    from vllm_amd.worker import PushAllReduce
+    dev = torch.device("cuda:0")
+    ranks = PushAllReduce.local_ranks(2, 1 << 16)
+    try:
+        x = torch.ones(4096, dtype=torch.float16, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ranks[0](x)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        done, gave_up = ranks[0].status()
+        assert done == 1 and gave_up >= 1, (done, gave_up)
+        assert 1.5 < first < 6.0, first
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ranks[0](x)
+        torch.cuda.synchronize()
+        later = time.perf_counter() - t0
+        done2, gave_up2 = ranks[0].status()
+        assert done2 == 21 and gave_up2 > gave_up, (done2, gave_up2)
+        assert later < 0.5, later
+    finally:
+        for r in ranks:
+            r.close()
+
+
 _IPC_WORKER = textwrap.dedent("""
     import os, sys
     sys.path.insert(0, os.getcwd())

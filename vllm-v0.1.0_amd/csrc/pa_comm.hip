@@ -30,7 +30,9 @@
 // to be acknowledged (s_waitcnt vmcnt(0)) before its workgroup counts as arrived, and the
 // flags are relaxed system-scope atomics in uncached memory.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
 // peers never arrive gives up, counts a timeout that pa_comm_status reports, and finishes the
-// launch with a meaningless result rather than hanging the GPU.
+// launch with a meaningless result rather than hanging the GPU.  From then on the communicator
+// is broken for good: later reduces on it wait for nobody (and keep counting), so the cost of a
+// dead peer is one bounded wait, not one per reduce; recovery is a new communicator.
 //
 // The sequence number lives in device memory, not in the kernel arguments, so a captured launch
 // can be replayed from a HIP graph.
@@ -159,12 +161,14 @@ __device__ __forceinline__ void arrive_and_signal(const CommArgs& a, uint32_t* c
 }
 
 // Waits until every peer's flag `flag0 + peer` here has reached k (flags only grow), or gives up.
-__device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl, int flag0, uint32_t k) {
+// `broken`: a wait of an earlier launch was given up.  The communicator stays broken from then on
+// and waits for nobody, so that a dead peer costs one bounded wait, not one per reduce.
+__device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl, int flag0, uint32_t k, bool broken) {
   const int tid = threadIdx.x;
   if (tid < a.world && tid != a.rank) {
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
-      if (wall_clock64() - t0 > kWaitTicks) {
+      if (broken || wall_clock64() - t0 > kWaitTicks) {
         __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -193,6 +197,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
   uint32_t* ctrl = a.ctrl[a.rank];
   // written by the last workgroup of the previous reduce (or zero): stable for this whole launch
   const uint32_t k = __hip_atomic_load(&ctrl[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const bool broken = __hip_atomic_load(&ctrl[kTimeouts], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   const size_t parity_off = (size_t)(k & 1u) * a.world * a.slot_bytes;
   u32x4* data = static_cast<u32x4*>(a.data);
   const size_t first = (size_t)blockIdx.x * kCommThreads + tid;
@@ -211,7 +216,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
     // 2. wait for every peer's contribution to this reduce
-    wait_for_peers(a, ctrl, kFlag0, k);
+    wait_for_peers(a, ctrl, kFlag0, k, broken);
     // 3. sum the contributions in rank order, in place over this rank's own
     for (size_t i = first; i < a.n16; i += stride) {
       float acc[Acc<T>::N];
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
       if (c != a.rank) store_shared(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16, data[i]);
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
-    wait_for_peers(a, ctrl, kFlag0, k);
+    wait_for_peers(a, ctrl, kFlag0, k, broken);
     // 2. sum the chunk this rank owns, in rank order; keep it and push it to every peer
     const size_t lo = (size_t)a.rank * q, hi = lo + q < a.n16 ? lo + q : a.n16;
     for (size_t i = lo + first; i < hi; i += stride) {
@@ -251,7 +256,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
       }
     }
     arrive_and_signal(a, ctrl, kArrivedB, kFlagB0, k, &last_to_arrive);
-    wait_for_peers(a, ctrl, kFlagB0, k);
+    wait_for_peers(a, ctrl, kFlagB0, k, broken);
     // 3. bring the other owners' sums home
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
