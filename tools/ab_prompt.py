@@ -58,7 +58,11 @@ def main():
                 assert rc == 0, lib.pa_last_error()
             call(); torch.cuda.synchronize()
             chk = out.float().abs().mean().item()
-            ref = chk if ref is None else ref
+            if ref is None:
+                ref = out.clone()
+                same = "reference"
+            else:
+                same = "identical" if torch.equal(out, ref) else f"max diff {(out.float() - ref.float()).abs().max().item():.3e}"
             s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 call()
@@ -66,7 +70,7 @@ def main():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for _ in range(3): call()
-            graphs[name] = (g, chk)
+            graphs[name] = (g, chk, same)
         times = {n_: [] for n_ in names}
         for _ in range(args.rounds):
             for name in names:
@@ -76,6 +80,6 @@ def main():
                 times[name].append(a.elapsed_time(b) / 3 * 1e3)
         for name in names:
             t = sorted(times[name])[len(times[name]) // 2]
-            print(f"{shape:9s} {args.dtype:9s} {name:12s} {t:9.1f} us  {flops / t / 1e6:7.1f} TFLOP/s   mean|out| {graphs[name][1]:.5f}", flush=True)
+            print(f"{shape:9s} {args.dtype:9s} {name:12s} {t:9.1f} us  {flops / t / 1e6:7.1f} TFLOP/s   mean|out| {graphs[name][1]:.5f}  {graphs[name][2]}", flush=True)
 
 main()

@@ -102,7 +102,11 @@ constexpr float kDeferLog2 = 5.f;
 #ifndef PA_PROMPT_PREFETCH
 #define PA_PROMPT_PREFETCH 4
 #endif
-constexpr int kPrefetch = PA_PROMPT_PREFETCH;  // K fragments in flight ahead of their MFMA
+#ifndef PA_PROMPT_PREFETCH_TIGHT
+#define PA_PROMPT_PREFETCH_TIGHT 3
+#endif
+// K fragments in flight ahead of their MFMA: PA_PROMPT_PREFETCH, or _TIGHT where the register
+// budget is cut for more than two waves per SIMD
 
 template <typename X, int D, int NW>
 struct PromptGeometry {
@@ -131,11 +135,14 @@ struct PromptGeometry {
   static constexpr bool UNIFORM_ROWS = THREADS % CPR == 0;
   static constexpr int ROWS_PER_PASS = THREADS / CPR;
   static constexpr int NQ = F32 ? D / 2 : D / 4;  // dwords of q per lane
+  // Waves per SIMD the register budget is cut for.  At head size 64 the 16-bit kernel fits 128
+  // registers, and two 8-wave workgroups then share a CU (their LDS images are 42 KiB each).
+  static constexpr int MIN_WAVES = (!F32 && D == 64 && NW == 8) ? 4 : 2;
   static_assert(KBYTES % 16 == 0 && VSTR % 16 == 0, "images must keep 16-byte alignment");
 };
 
 template <typename X, int D, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void pa_prompt_kernel(const PromptArgs a) {
+__global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) void pa_prompt_kernel(const PromptArgs a) {
   using G = PromptGeometry<X, D, NW>;
   constexpr int THREADS = G::THREADS, kQBlock = G::QBLOCK;
   constexpr int ES = G::ES;
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(64 * NW, 2) void pa_prompt_kernel(const PromptArgs 
   constexpr int CPR = G::CPR, TOTAL = G::TOTAL, NCH = G::NCH, NQ = G::NQ;
   extern __shared__ __align__(16) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what depends on the wave only stays out of the vector registers
   const int r = lane & 31, hh = lane >> 5;
   const unsigned wi = blockIdx.x / (unsigned)a.num_heads;
   const int head = (int)(blockIdx.x - wi * (unsigned)a.num_heads);
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pa_prompt_kernel(const PromptArgs 
         // K fragments are fetched kPrefetch k-steps ahead of the MFMA that
         // consumes them, so the LDS latency overlaps the matrix pipe.
         constexpr int KS = D / 16, NS = KB * KS;
+        constexpr int kPrefetch = G::MIN_WAVES > 2 ? PA_PROMPT_PREFETCH_TIGHT : PA_PROMPT_PREFETCH;
         const unsigned char* krow = kimg + r * KSTR + 16 * hh;
         u32x4 kf[NS];
 #pragma unroll
@@ -394,13 +403,24 @@ __global__ __launch_bounds__(64 * NW, 2) void pa_prompt_kernel(const PromptArgs 
 #pragma unroll
         for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
         const u32x4 ones = {X::kOnes, X::kOnes, X::kOnes, X::kOnes};
+        // registers 8 s2 .. 8 s2 + 7 of block kb = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
+        auto pack_group = [&](int g) {
+          const int kb = g >> 1, s2 = g & 1;
+          return u32x4{X::pack2(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]), X::pack2(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]),
+                       X::pack2(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]), X::pack2(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7])};
+        };
+        // Where registers are short (MIN_WAVES > 2) all weights are converted before the first
+        // MFMA, which ends the 32 fp32 registers' lives there; else group by group between the MFMAs.
+        [[maybe_unused]] u32x4 pf_all[KB * 2];
+        if constexpr (G::MIN_WAVES > 2) {
+#pragma unroll
+          for (int g = 0; g < KB * 2; ++g) pf_all[g] = pack_group(g);
+        }
 #pragma unroll
         for (int g = 0; g < KB * 2; ++g) {
-          const int kb = g >> 1, s2 = g & 1;
           if (g + 1 < KB * 2) load_vt(vimg, g + 1, vt[g + 1]);  // next group's fragments behind this group's MFMAs
-          // registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
-          const u32x4 pf = {X::pack2(s[kb][8 * s2 + 0], s[kb][8 * s2 + 1]), X::pack2(s[kb][8 * s2 + 2], s[kb][8 * s2 + 3]),
-                            X::pack2(s[kb][8 * s2 + 4], s[kb][8 * s2 + 5]), X::pack2(s[kb][8 * s2 + 6], s[kb][8 * s2 + 7])};
+          u32x4 pf;
+          if constexpr (G::MIN_WAVES > 2) pf = pf_all[g]; else pf = pack_group(g);
           // row sums of the rounded weights: a block of ones as the A operand puts
           // sum_key P[key][q] (all 64 lanes' keys) into every register of lsum
           lsum = X::mfma(ones, pf, lsum);
