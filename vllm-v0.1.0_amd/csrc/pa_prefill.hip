@@ -102,6 +102,9 @@ constexpr float kDeferLog2 = 5.f;
 #ifndef PA_PROMPT_PREFETCH
 #define PA_PROMPT_PREFETCH 4
 #endif
+#ifndef PA_PROMPT_CLUSTER_PRIO
+#define PA_PROMPT_CLUSTER_PRIO 1
+#endif
 #ifndef PA_PROMPT_PREFETCH_TIGHT
 #define PA_PROMPT_PREFETCH_TIGHT 3
 #endif
@@ -137,6 +140,10 @@ struct PromptGeometry {
   static constexpr int NQ = F32 ? D / 2 : D / 4;  // dwords of q per lane
   // Waves per SIMD the register budget is cut for.  At head size 64 the 16-bit kernel fits 128
   // registers, and two 8-wave workgroups then share a CU (their LDS images are 42 KiB each).
+  // An 8-wave workgroup's two waves per SIMD compete for issue slots: a wave inside one of its
+  // MFMA clusters (S^T, O^T) runs at priority 1, so the partner's softmax fills the gaps
+  // between its MFMAs instead of delaying them (+1 % on long prompts; nothing at 4 waves).
+  static constexpr bool CLUSTER_PRIO = PA_PROMPT_CLUSTER_PRIO && NW == 8 && !F32;
   static constexpr int MIN_WAVES = (!F32 && D == 64 && NW == 8) ? 4 : 2;
   static_assert(KBYTES % 16 == 0 && VSTR % 16 == 0, "images must keep 16-byte alignment");
 };
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         constexpr int kPrefetch = G::MIN_WAVES > 2 ? PA_PROMPT_PREFETCH_TIGHT : PA_PROMPT_PREFETCH;
         const unsigned char* krow = kimg + r * KSTR + 16 * hh;
         u32x4 kf[NS];
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int st = 0; st < kPrefetch && st < NS; ++st)
           kf[st] = *(const u32x4*)(krow + (st / KS) * 32 * KSTR + (st % KS) * 32);
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kPrefetch, 0);
 #endif
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
       }
 
       // causal mask on the tiles that reach the diagonal (this also hides the
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
         const u32x4 ones = {X::kOnes, X::kOnes, X::kOnes, X::kOnes};
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
         // registers 8 s2 .. 8 s2 + 7 of block kb = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
         auto pack_group = [&](int g) {
           const int kb = g >> 1, s2 = g & 1;
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
           }
         }
 #endif
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
         l = l * alpha + lsum[0];
       }
     }
@@ -521,7 +532,11 @@ int dispatch_dtype(PromptArgs& args, int num_work, int head_size, int dtype, hip
 // for twice as many rows, which is worth it once the grid still fills the chip
 // several times over; smaller batches keep 128 rows for the finer grain.
 int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
+#ifdef PA_PROMPT_FORCE_WAVES
+  static const int forced = PA_PROMPT_FORCE_WAVES;
+#else
   static const int forced = tuning_int("PA_PROMPT_WAVES", 0);  // tuning builds: 4 or 8
+#endif
   if (forced == 4 || forced == 8) return forced;
   int64_t big_blocks = 0;
   for (int s = 0; s < num_seqs; ++s) big_blocks += (cu[s + 1] - cu[s] + 255) / 256;
