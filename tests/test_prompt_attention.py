@@ -298,6 +298,7 @@ def test_kernel_on_scores_that_drive_the_running_maximum(pkg, dtype):
     ("bfloat16", 32, 80, [700] * 11 + [1]),
     ("float16", 40, 64, [300, 513, 256, 1000, 255, 257, 2048, 31, 777]),
     ("float32", 32, 96, [520] * 11),
+    ("bfloat16", 32, 64, [2048] * 4 + [100]),   # head size 64: two 8-wave workgroups share a CU
 ])
 def test_kernel_with_256_row_workgroups_against_torch(pkg, dtype_name, H, D, lens):
     """Batches big enough for the 8-wave (256 query rows) workgroups, with
