@@ -414,11 +414,11 @@ int pa_silu_and_mul(
  *                    must issue the same sequence of reduces.  Reduces of one
  *                    communicator must not overlap in time (one stream, or
  *                    event-ordered).  A rank whose peers do not arrive within
- *                    two seconds gives up the wait, finishes the launch with a
- *                    meaningless result and counts a timeout; the communicator
- *                    is broken from then on (later reduces on it wait for
- *                    nobody and keep counting: a dead peer costs one bounded
- *                    wait, not one per reduce) and must be replaced.
+ *                    two seconds gives up the wait, fills its result with NaN
+ *                    and counts a timeout; the communicator is broken from
+ *                    then on (later reduces on it wait for nobody, return NaN
+ *                    and keep counting: a dead peer costs one bounded wait,
+ *                    not one per reduce) and must be replaced.
  *   pa_comm_status   synchronous read-back: reduces completed, timeouts.
  */
 #define PA_COMM_HANDLE_BYTES 128

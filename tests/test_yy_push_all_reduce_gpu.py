@@ -73,8 +73,8 @@ def test_ranks_on_one_gpu_by_pointer(pkg, world, algorithm):
 
 
 def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
-    """Rank 1 of two never launches: rank 0's first reduce gives up after the two-second bound and
-    counts it, and every later reduce of that communicator returns without waiting at all."""
+    """Rank 1 of two never launches: rank 0's first reduce gives up after the two-second bound, counts
+    it and returns NaNs, and every later reduce of that communicator does the same without waiting."""
     import time
     import torch
     from vllm_amd.worker import PushAllReduce
@@ -90,6 +90,8 @@ def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
         done, gave_up = ranks[0].status()
         assert done == 1 and gave_up >= 1, (done, gave_up)
         assert 1.5 < first < 6.0, first
+        assert bool(torch.isnan(x).all())          # never a plausible-looking partial sum
+        x.fill_(1.0)
         t0 = time.perf_counter()
         for _ in range(20):
             ranks[0](x)
@@ -98,6 +100,7 @@ def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
         done2, gave_up2 = ranks[0].status()
         assert done2 == 21 and gave_up2 > gave_up, (done2, gave_up2)
         assert later < 0.5, later
+        assert bool(torch.isnan(x).all())
     finally:
         for r in ranks:
             r.close()

@@ -30,8 +30,8 @@
 // to be acknowledged (s_waitcnt vmcnt(0)) before its workgroup counts as arrived, and the
 // flags are relaxed system-scope atomics in uncached memory.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
 // peers never arrive gives up, counts a timeout that pa_comm_status reports, and finishes the
-// launch with a meaningless result rather than hanging the GPU.  From then on the communicator
-// is broken for good: later reduces on it wait for nobody (and keep counting), so the cost of a
+// launch with a result of NaNs rather than hanging the GPU.  From then on the communicator
+// is broken for good: later reduces on it wait for nobody (NaN results, counted), so the cost of a
 // dead peer is one bounded wait, not one per reduce; recovery is a new communicator.
 //
 // The sequence number lives in device memory, not in the kernel arguments, so a captured launch
@@ -79,6 +79,7 @@ struct CommArgs {
 template <typename T> struct Acc;
 template <> struct Acc<float> {
   static constexpr int N = 4;
+  static constexpr uint32_t kNaN = 0x7fc00000u;
   static __device__ __forceinline__ void add(float* acc, u32x4 v) {
 #pragma unroll
     for (int i = 0; i < 4; i++) acc[i] += __uint_as_float(v[i]);
@@ -89,6 +90,7 @@ template <> struct Acc<float> {
 };
 template <> struct Acc<_Float16> {
   static constexpr int N = 8;
+  static constexpr uint32_t kNaN = 0x7e007e00u;
   static __device__ __forceinline__ void add(float* acc, u32x4 v) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -109,6 +111,7 @@ template <> struct Acc<_Float16> {
 };
 template <> struct Acc<__bf16> {
   static constexpr int N = 8;
+  static constexpr uint32_t kNaN = 0x7fc07fc0u;
   static __device__ __forceinline__ void add(float* acc, u32x4 v) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -163,13 +166,15 @@ __device__ __forceinline__ void arrive_and_signal(const CommArgs& a, uint32_t* c
 // Waits until every peer's flag `flag0 + peer` here has reached k (flags only grow), or gives up.
 // `broken`: a wait of an earlier launch was given up.  The communicator stays broken from then on
 // and waits for nobody, so that a dead peer costs one bounded wait, not one per reduce.
-__device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl, int flag0, uint32_t k, bool broken) {
+__device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl, int flag0, uint32_t k, bool broken,
+                                               int* gave_up) {
   const int tid = threadIdx.x;
   if (tid < a.world && tid != a.rank) {
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
       if (broken || wall_clock64() - t0 > kWaitTicks) {
         __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *gave_up = 1;  // LDS; every writer stores the same value
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -193,7 +198,9 @@ __device__ __forceinline__ void finish(uint32_t* ctrl, uint32_t k) {
 template <typename T, bool TWO_SHOT>
 __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const CommArgs a) {
   __shared__ int last_to_arrive;
+  __shared__ int gave_up;  // a wait of this workgroup ended without its peer
   const int tid = threadIdx.x;
+  if (tid == 0) gave_up = 0;
   uint32_t* ctrl = a.ctrl[a.rank];
   // written by the last workgroup of the previous reduce (or zero): stable for this whole launch
   const uint32_t k = __hip_atomic_load(&ctrl[kSeq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -216,7 +223,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
     // 2. wait for every peer's contribution to this reduce
-    wait_for_peers(a, ctrl, kFlag0, k, broken);
+    wait_for_peers(a, ctrl, kFlag0, k, broken, &gave_up);
     // 3. sum the contributions in rank order, in place over this rank's own
     for (size_t i = first; i < a.n16; i += stride) {
       float acc[Acc<T>::N];
@@ -237,7 +244,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
       if (c != a.rank) store_shared(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16, data[i]);
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
-    wait_for_peers(a, ctrl, kFlag0, k, broken);
+    wait_for_peers(a, ctrl, kFlag0, k, broken, &gave_up);
     // 2. sum the chunk this rank owns, in rank order; keep it and push it to every peer
     const size_t lo = (size_t)a.rank * q, hi = lo + q < a.n16 ? lo + q : a.n16;
     for (size_t i = lo + first; i < hi; i += stride) {
@@ -256,13 +263,19 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
       }
     }
     arrive_and_signal(a, ctrl, kArrivedB, kFlagB0, k, &last_to_arrive);
-    wait_for_peers(a, ctrl, kFlagB0, k, broken);
+    wait_for_peers(a, ctrl, kFlagB0, k, broken, &gave_up);
     // 3. bring the other owners' sums home
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
       if (c != a.rank)
         data[i] = load_shared(mine + (size_t)c * a.slot_bytes + (q + (i - (size_t)c * q)) * 16);
     }
+  }
+  // A reduce that did not hear from every peer must not pass for a sum: this workgroup's part of
+  // the result becomes NaN (every workgroup waits for the same flags, so all of them get here).
+  if (gave_up) {
+    const u32x4 nan = {Acc<T>::kNaN, Acc<T>::kNaN, Acc<T>::kNaN, Acc<T>::kNaN};
+    for (size_t i = first; i < a.n16; i += stride) data[i] = nan;
   }
   finish(ctrl, k);
 }

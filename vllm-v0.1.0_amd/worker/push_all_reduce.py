@@ -122,7 +122,9 @@ class PushAllReduce:
         _capi.comm_all_reduce(self._comm, t, torch.cuda.current_stream(self.device), self.algorithm)
 
     def status(self):
-        """(reduces completed, waits given up); synchronises with the device."""
+        """(reduces completed, waits given up); synchronises with the device.  A reduce whose wait was
+        given up (a peer did not arrive within two seconds) returns NaNs, and so does every later one
+        on this object: replace it."""
         with torch.cuda.device(self.device):
             return _capi.comm_status(self._comm)
 
