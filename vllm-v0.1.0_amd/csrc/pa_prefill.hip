@@ -468,23 +468,41 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
 
   // ---- epilogue --------------------------------------------------------------
   if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
-  if (q0 + r < n) {
-    const float inv = 1.f / l;
-    unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
+  const float inv = 1.f / l;
+  unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
+  if constexpr (F32) {
+    if (q0 + r < n) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * db + 8 * g + 4 * hh;  // registers 4g..4g+3 = rows d..d+3 of O^T
+          if (d < D)
+            *(f32x4*)(orow + d * 4) = f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+        }
+    }
+  } else {
+    // Registers 4g..4g+3 of a lane are rows 8g + 4hh + 0..3 of the d block: 8 bytes of the output
+    // row, the other 8 of the same 16 sit in lane l ^ 32.  Two v_permlane32_swap per pair of
+    // groups give lanes 0-31 the 16 bytes of group g and lanes 32-63 those of group g + 1, so the
+    // row goes out in 16-byte stores, half as many.  (Every lane takes part in the swaps; only
+    // the stores are masked.)
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 32 * db + 8 * g + 4 * hh;  // registers 4g..4g+3 = rows d..d+3 of O^T
-        if (d < D) {
-          const float v0 = o[db][4 * g] * inv, v1 = o[db][4 * g + 1] * inv, v2 = o[db][4 * g + 2] * inv,
-                      v3 = o[db][4 * g + 3] * inv;
-          if constexpr (F32) {
-            *(f32x4*)(orow + d * 4) = f32x4{v0, v1, v2, v3};
-          } else {
-            *(u32x2*)(orow + d * 2) = u32x2{X::pack2(v0, v1), X::pack2(v2, v3)};
-          }
-        }
+      for (int gp = 0; gp < 2; ++gp) {
+        const int g = 2 * gp;
+        const uint32_t x0 = X::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+        const uint32_t x1 = X::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        const uint32_t y0 = X::pack2(o[db][4 * g + 4] * inv, o[db][4 * g + 5] * inv);
+        const uint32_t y1 = X::pack2(o[db][4 * g + 6] * inv, o[db][4 * g + 7] * inv);
+        // swap(old, src): old keeps its lanes 0-31 and takes src's lanes 0-31 into its lanes 32-63;
+        // src takes old's lanes 32-63 into its lanes 0-31 and keeps its lanes 32-63
+        const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+        const int d = 32 * db + 8 * (g + hh);
+        if (d < D && q0 + r < n)
+          *(u32x4*)(orow + d * 2) = u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
       }
   }
 }
