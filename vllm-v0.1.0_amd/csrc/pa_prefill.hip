@@ -130,7 +130,12 @@ struct PromptGeometry {
   static constexpr int KBYTES = KT * KSTR;
   static constexpr int VBYTES = KT * VSTR;
   static constexpr int BUF = KBYTES + VBYTES;
-  static constexpr int LDS_BYTES = 2 * BUF;
+  // Epilogue of the 16-bit kernels: a wave's 32 output rows pass through a strip of LDS of its
+  // own (row stride OSTR: 16-byte writes by 8 lanes on 8 rows spread over all banks) so that
+  // they leave as whole rows.
+  static constexpr int OSTR = D * 2 + 16;
+  static constexpr int OUT_BYTES = F32 ? 0 : NW * 32 * OSTR;
+  static constexpr int LDS_BYTES = 2 * BUF > OUT_BYTES ? 2 * BUF : OUT_BYTES;
   static constexpr int CPR = D * ES / 16;    // 16-byte chunks per row
   static constexpr int TOTAL = KT * CPR;
   static constexpr int NCH = (TOTAL + THREADS - 1) / THREADS;
@@ -469,9 +474,9 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   // ---- epilogue --------------------------------------------------------------
   if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
   const float inv = 1.f / l;
-  unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
   if constexpr (F32) {
     if (q0 + r < n) {
+      unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -484,9 +489,13 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   } else {
     // Registers 4g..4g+3 of a lane are rows 8g + 4hh + 0..3 of the d block: 8 bytes of the output
     // row, the other 8 of the same 16 sit in lane l ^ 32.  Two v_permlane32_swap per pair of
-    // groups give lanes 0-31 the 16 bytes of group g and lanes 32-63 those of group g + 1, so the
-    // row goes out in 16-byte stores, half as many.  (Every lane takes part in the swaps; only
-    // the stores are masked.)
+    // groups give lanes 0-31 the 16 bytes of group g and lanes 32-63 those of group g + 1.  The
+    // 16-byte pieces go to the wave's LDS strip (every wave is past the loop's last barrier, so
+    // the K/V images are dead) and come back with LPR lanes per row: global stores of whole
+    // rows instead of 64 pieces in 32 rows per instruction.
+    constexpr int OSTR = G::OSTR;
+    unsigned char* strip = smem + wave * 32 * OSTR;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -501,9 +510,21 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
         const int d = 32 * db + 8 * (g + hh);
-        if (d < D && q0 + r < n)
-          *(u32x4*)(orow + d * 2) = u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+        if (d < D) *(u32x4*)(strip + r * OSTR + d * 2) = u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
       }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = CPR <= 8 ? 8 : 16;  // lanes per output row (CPR of them store)
+    constexpr int RPI = 64 / LPR;           // rows per store instruction
+    const int chunk = lane % LPR;
+    unsigned char* obase = (unsigned char*)a.out + ((t0 + q0) * a.num_heads + head) * (int64_t)D * ES;
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+      const int row = i * RPI + lane / LPR;
+      if (chunk < CPR && q0 + row < n) {
+        const u32x4 v = *(const u32x4*)(strip + row * OSTR + chunk * 16);
+        *(u32x4*)(obase + (int64_t)row * a.num_heads * D * ES + chunk * 16) = v;
+      }
+    }
   }
 }
 
