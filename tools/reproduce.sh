@@ -27,3 +27,18 @@ python -u tools/bench_throughput.py --json gpurun_out/throughput_7b.json        
 #   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
 #   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
 #   python tools/summarize_profiles.py gpurun_out/prof <tag>
+# Round 2:
+python -u tools/sweep_decode.py --planned --graph   | tee gpurun_out/sweep_decode_planned.log   # profiles/r02p_decode_sweep.txt
+python -u tools/bench_append_decode.py              | tee gpurun_out/append_decode.log          # profiles/r02u_append_form_experiments.txt
+python -u tools/bench_rotary_cache.py               | tee gpurun_out/rotary_cache.log           # profiles/r02n_rotary_cache.txt
+python -u tools/exp_cache_placement.py              | tee gpurun_out/cache_placement.log        # profiles/r02z_cache_placement.txt
+python -u tools/exp_all_reduce_beside_decode.py     | tee gpurun_out/all_reduce_beside.log      # profiles/r02z_all_reduce_beside_decode.txt
+python -u tools/bench_prompt.py                     | tee gpurun_out/bench_prompt_r02.log       # profiles/r02zz_prompt_attention_bench.txt
+python -u bench.py --roofline-only                  | tee gpurun_out/bench_roofline_only.json   # isolated decode launches (rocprofv3 median: tools/kernel_trace_median.py)
+#   several ranks sharing the one card (rendezvous over gloo, peers through IPC):
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29517 tools/stress_push_all_reduce.py
+#   A/B of library variants built with `make -C vllm-v0.1.0_amd/csrc variant NAME=x EXTRA_HIPFLAGS=-D...`:
+#   python tools/ab_decode.py --libs default,x --planned ; python tools/ab_prompt.py --libs default,x
+#   registers / spills / scratch of every kernel of a source file: python tools/kernel_resources.py vllm-v0.1.0_amd/csrc/pa_prefill.hip
+#   PMC passes over the prompt kernel (profiles/r02zz_prompt_pmc_cycles.txt):
+#   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/p1 -- python3 tools/prof_prompt.py bfloat16 1 16384
