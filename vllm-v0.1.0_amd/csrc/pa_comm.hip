@@ -338,7 +338,11 @@ extern "C" int pa_comm_create(int rank, int world, size_t max_bytes, pa_comm** c
   hipError_t e = hipGetDevice(&c->device);
   if (e == hipSuccess) e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->ctrl), 256, hipDeviceMallocUncached);
   if (e == hipSuccess) e = hipMemset(c->ctrl, 0, 256);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->inbox), 2 * (size_t)world * c->slot_bytes);
+  // The inbox is written by other devices while kernels of this one read it: fine-grained memory
+  // is what the runtime keeps coherent between devices during a kernel (the accesses themselves
+  // are system-scope atomics either way).
+  if (e == hipSuccess)
+    e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->inbox), 2 * (size_t)world * c->slot_bytes, hipDeviceMallocFinegrained);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     const size_t inbox_bytes = 2 * (size_t)world * c->slot_bytes;
