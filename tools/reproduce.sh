@@ -27,7 +27,7 @@ python -u tools/bench_throughput.py --json gpurun_out/throughput_7b.json        
 #   rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
 #   rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --layers 4
 #   python tools/summarize_profiles.py gpurun_out/prof <tag>
-# Round 2:
+# Later measurements:
 python -u tools/sweep_decode.py --planned --graph   | tee gpurun_out/sweep_decode_planned.log   # profiles/r02p_decode_sweep.txt
 python -u tools/bench_append_decode.py              | tee gpurun_out/append_decode.log          # profiles/r02u_append_form_experiments.txt
 python -u tools/bench_rotary_cache.py               | tee gpurun_out/rotary_cache.log           # profiles/r02n_rotary_cache.txt
