@@ -51,6 +51,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -124,6 +125,8 @@ def parse_args(argv=None):
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-c2", action="store_true", help="skip the secondary microbench-shape measurement")
     p.add_argument("--no-tp-leg", action="store_true", help="N > 1 without --tp: skip the extra head-sharded measurement")
+    p.add_argument("--tp-leg-deadline", type=float, default=180.0,
+                   help="N > 1 without --tp: seconds the extra head-sharded legs may take before the line is printed without them")
     p.add_argument("--tp-graph", action="store_true",
                    help="tensor-parallel legs: replay the all-reduce from a HIP graph captured on the side stream "
                         "(default: direct RCCL calls on the side stream; the graph path has only been exercised with a "
@@ -713,9 +716,37 @@ def main(argv=None):
         extra["c2"] = c2
         del w2, ws2
 
+    def emit():
+        if dist.rank == 0:
+            config = {
+                "workload": f"{model_name} decode hot path: {L} layers x (reshape_and_cache + single_query_cached_kv_attention), "
+                            f"batch {S} per GPU, {H} heads x {D}, block {B}, ctx {CTX}, "
+                            f"distinct physical blocks, per-layer 2x{w.cache_bytes / 2 / 2**30:.2f} GiB caches",
+                "batch_per_gpu": S, "num_heads": H, "head_size": D, "block_size": B, "context_len": CTX,
+                "layers": L, "sharding": "independent replicas per GPU (no data-path collective); "
+                                         "the head-sharded form is in \"tp\" (N > 1) or under --tp",
+            }
+            print(json.dumps(result_line(args, dist.world, elapsed, units, "tokens/s", config, extra,
+                                         metric_text(args, model_name, 1))), flush=True)
+
     # ---- N > 1: the head-sharded form measured in the same process ---------------------------------
     if dist.active and not args.no_tp_leg and H % dist.world == 0:
-        # an extra measurement: whatever goes wrong in it must not cost the line above
+        # An extra measurement: whatever goes wrong in it must not cost the line above.  Errors are
+        # caught below; against a HANG (a collective that some rank never enters) every rank runs a
+        # deadline: when it passes, rank 0 prints the line with what it has and all ranks leave.
+        line_lock = threading.Lock()  # held by whoever prints the line
+
+        def expire():
+            if line_lock.acquire(blocking=False):
+                for leg in ("tp", "tp_push"):
+                    if leg == "tp" or args.tp_collective != "push":
+                        extra.setdefault(leg, {"error": f"did not finish within the {args.tp_leg_deadline:.0f} s deadline of the extra legs"})
+                emit()
+            os._exit(0)
+
+        deadline = threading.Timer(args.tp_leg_deadline, expire)
+        deadline.daemon = True
+        deadline.start()
         progress(dist, "head-sharded leg")
         try:
             tp_elapsed, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w)
@@ -731,22 +762,15 @@ def main(argv=None):
                 extra["tp_push"] = info
             except Exception as e:  # noqa: BLE001
                 extra["tp_push"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        if not line_lock.acquire(blocking=False):
+            time.sleep(3600)  # the deadline passed at this very moment: its thread prints and ends the process
+        deadline.cancel()
 
     # ---- CPU baseline --------------------------------------------------------------------------------
     if not args.no_cpu_baseline and dist.rank == 0 and dist.world == 1:
         extra["cpu_baseline"] = cpu_baseline(torch, np, args, w, L, attention_ops)
 
-    if dist.rank == 0:
-        config = {
-            "workload": f"{model_name} decode hot path: {L} layers x (reshape_and_cache + single_query_cached_kv_attention), "
-                        f"batch {S} per GPU, {H} heads x {D}, block {B}, ctx {CTX}, "
-                        f"distinct physical blocks, per-layer 2x{w.cache_bytes / 2 / 2**30:.2f} GiB caches",
-            "batch_per_gpu": S, "num_heads": H, "head_size": D, "block_size": B, "context_len": CTX,
-            "layers": L, "sharding": "independent replicas per GPU (no data-path collective); "
-                                     "the head-sharded form is in \"tp\" (N > 1) or under --tp",
-        }
-        print(json.dumps(result_line(args, dist.world, elapsed, units, "tokens/s", config, extra,
-                                     metric_text(args, model_name, 1))))
+    emit()
     dist.close()
 
 

@@ -188,3 +188,31 @@ def test_bench_head_sharded_step_with_the_push_collective_two_ranks_on_one_gpu(p
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["tp"]["tp"] == 2 and "push" in d["tp"]["all_reduce_collective"]
     assert d["tp"]["push_waits_given_up"] == 0 and d["tp"]["push_reduces_done"] > 0
+
+
+@pytest.mark.parametrize("deadline", [180.0, 0.001])
+def test_bench_default_multi_rank_run_reports_both_head_sharded_legs_or_gives_up_on_time(pkg, deadline):
+    """bench.py --gpus 2 without --tp (what the driver's scaling run launches), both ranks on the one card:
+    the line carries the replica measurement plus the head-sharded step with the backend's all-reduce ("tp")
+    and with the push all-reduce ("tp_push").  With a deadline that has passed before the extra legs start,
+    the line still comes out, once, from rank 0, with the legs marked unfinished, and every rank exits 0."""
+    import json
+    import subprocess
+    import sys
+    from tests.test_all_reduce import ROOT, _free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--layers", "2", "--batch", "32", "--ctx", "256", "--dist-backend", "gloo",
+           "--no-c2", "--no-cpu-baseline", "--no-roofline", "--tp-leg-deadline", str(deadline)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    if deadline > 1:
+        assert d["tp"]["tp"] == 2 and d["tp"]["value"] > 0, d["tp"]
+        assert d["tp_push"]["push_waits_given_up"] == 0 and d["tp_push"]["push_reduces_done"] > 0, d["tp_push"]
+    else:
+        assert "deadline" in d["tp"]["error"] and "deadline" in d["tp_push"]["error"]
