@@ -92,6 +92,30 @@ def cache_case(pkg, seed):
             assert np.array_equal(datagen.torch_to_storage(vcs[l], dtype), vref[l]), what + f": copy_blocks value layer {l}"
 
 
+def rotary_cache_case(pkg, seed):
+    """Random shape of rotary_embedding_neox + reshape_and_cache in one call (full and partial rotary,
+    decode-sized and other batches, tokens sharing a block, tokens without a slot), bit for bit
+    against the oracle's two steps."""
+    import numpy as np
+    from tests import test_rotary_cache_gpu as t
+    rng = np.random.default_rng(11000 + seed)
+    dtype = ["float16", "bfloat16", "float32"][seed % 3]
+    D, B = int(rng.choice([64, 80, 96, 128])), int(rng.choice([8, 16, 32]))
+    H = int(rng.choice([1, 2, 5, 8, 12]))
+    T = int(rng.choice([1, 7, 16, 33, 100, 256, 511, 520]))
+    x = 8 if dtype != "float32" else 4
+    rot = int(rng.choice([D, D // 2, D // 4, 2 * x, 4 * x]))  # halves that are whole vectors; others are in the test suite
+    NB = T + 3
+    slots = None
+    if rng.random() < 0.5:
+        blocks = rng.permutation(NB)[:T]
+        slots = (blocks * B + rng.integers(0, B, size=T)).astype(np.int32)
+        if T > 2:
+            slots[1] = slots[0] - 1 if slots[0] % B else slots[0] + 1   # two tokens in one block
+            slots[T // 2] = -1                                           # a token without a slot
+    t._check(pkg, dtype, T, H, D, B, rot, NB, seed=seed, slots=slots, via="capi" if seed % 2 else "module")
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
@@ -102,7 +126,7 @@ def main():
     for seed in range(first, first + count):
         for name, fn in (("decode", test_decode_gpu.test_decode_randomized_shapes_against_oracle),
                          ("prompt", test_prompt_attention.test_kernel_randomized_shapes_against_oracle),
-                         ("append", append_case), ("cache", cache_case)):
+                         ("append", append_case), ("cache", cache_case), ("rotary+cache", rotary_cache_case)):
             try:
                 fn(pkg, seed)
             except AssertionError as e:
@@ -110,7 +134,7 @@ def main():
                 print(f"FAIL {name} seed {seed}: {str(e)[:300]}", flush=True)
         if (seed - first + 1) % 10 == 0:
             print(f"  {seed - first + 1} seeds, {len(failures)} failures, {time.time() - t0:.0f} s", flush=True)
-    print(f"seeds {first}..{first + count - 1}: decode, prompt attention, the append form and the cache operators against the oracle, {len(failures)} failures")
+    print(f"seeds {first}..{first + count - 1}: decode, prompt attention, the append form, the cache operators and rotary + cache write against the oracle, {len(failures)} failures")
     return 1 if failures else 0
 
 
