@@ -22,7 +22,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU), two forms:
             (sequence, head) units are independent, no data-path collective;
             value aggregates all ranks ("scaling": "weak").  The line also
             carries a "tp" object: the head-sharded form below measured in the
-            same process.
+            same process with the backend's all-reduce, and "tp_push": the same
+            step with this package's own all-reduce, measured by one child
+            process per rank (a fault there cannot take the line with it).
   --tp      the reference's tensor parallelism: rank r owns heads
             [r*H/N, (r+1)*H/N) and their K/V; per layer reshape_and_cache +
             attention on the local heads, the row-parallel o_proj matmul into
@@ -135,6 +137,10 @@ def parse_args(argv=None):
                    help="tensor-parallel legs: 'backend' = all_reduce of --dist-backend (RCCL); 'push' = this package's "
                         "one-shot all-reduce over peer-mapped inboxes (worker/push_all_reduce.py), which also runs with "
                         "several ranks on one GPU")
+    p.add_argument("--rehearse-child-abort", type=int, default=-1, metavar="RANK",
+                   help="rehearsal: the push leg's child process of this rank aborts before it times anything (the "
+                        "line must still come out, with the leg marked failed)")
+    p.add_argument("--abort-before-timing", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--roofline-only", action="store_true",
                    help="launch nothing but isolated decode kernels (5 warm-ups + 40 timed): the command to put "
                         "under rocprofv3 --kernel-trace so that its per-dispatch median reproduces roofline.frac")
@@ -443,6 +449,8 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
             p.wait()
 
     progress(dist, f"tp leg: launcher ready ({'graph' if use_graph else 'direct'}); timing")
+    if args.abort_before_timing:
+        os.abort()  # rehearsal of a rank that dies in the leg
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
     progress(dist, f"tp leg timed: {elapsed * 1e3 / args.steps:.3f} ms")
     coll = ("one-shot push" if push is not None else "stand-in" if emulate else
@@ -487,6 +495,59 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
         dist.barrier()
         push.close()
     return elapsed, info, w
+
+
+CHILD = None  # the push leg's child process of this rank, while it runs (the deadline ends it)
+
+
+def push_leg_in_children(args, dist, device, budget_s):
+    """The head-sharded step with this package's own all-reduce, measured by CHILD processes: one
+    per rank, with a process group of their own, started as `bench.py --tp --tp-collective push`.
+    A multi-GPU box is the first place where those kernels store into another GPU's memory over
+    xGMI; a fault there ends the process it happens in, and that must not be the process that
+    holds the result line.  Returns the leg's info dict (rank 0) or {"error": ...}."""
+    global CHILD
+    import socket
+    import subprocess
+    port = 0.0
+    if dist.rank == 0:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = float(s.getsockname()[1])
+    port = int(dist.max_float(port, device))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        del env[k]  # with the agent's store flag set, rank 0 would look for a store nobody serves on the new port
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(dist.world), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--tp", "--tp-collective", "push", "--workload", args.workload,
+           "--batch", str(args.batch), "--ctx", str(args.ctx), "--block-size", str(args.block_size),
+           "--layers", str(args.layers), "--dtype", args.dtype, "--dist-backend", args.dist_backend,
+           "--no-cpu-baseline", "--no-roofline", "--no-c2"]
+    cmd += ["--tp-graph"] if args.tp_graph else []
+    cmd += ["--progress"] if args.progress else []
+    cmd += ["--abort-before-timing"] if args.rehearse_child_abort == dist.rank else []
+    CHILD = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = CHILD.communicate(timeout=max(budget_s, 20.0))
+        rc = CHILD.returncode
+    except subprocess.TimeoutExpired:
+        CHILD.kill()
+        out, err = CHILD.communicate()
+        rc = "timeout"
+    CHILD = None
+    if PROGRESS and err:
+        sys.stderr.write(err)
+    failed = dist.sum_float(0.0 if rc == 0 else 1.0, device)  # also: every rank's child has ended
+    where = "measured in child processes (one per rank, a process group of their own)"
+    if dist.rank != 0:
+        return None
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc != 0 or failed or len(lines) != 1:
+        return {"error": f"child processes of {int(failed)} of {dist.world} ranks failed; rank 0's child: exit {rc}, "
+                         f"stderr tail: {err[-300:]!r}", "where": where}
+    line = json.loads(lines[0])
+    info = dict(line["tp"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"], where=where)
+    return info
 
 
 def cpu_baseline(torch, np, args, w, L, attention_ops):
@@ -742,8 +803,11 @@ def main(argv=None):
                     if leg == "tp" or args.tp_collective != "push":
                         extra.setdefault(leg, {"error": f"did not finish within the {args.tp_leg_deadline:.0f} s deadline of the extra legs"})
                 emit()
+            if CHILD is not None:
+                CHILD.kill()
             os._exit(0)
 
+        t_legs = time.monotonic()
         deadline = threading.Timer(args.tp_leg_deadline, expire)
         deadline.daemon = True
         deadline.start()
@@ -755,11 +819,11 @@ def main(argv=None):
             extra["tp"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         if args.tp_collective != "push":
             # the same step with this package's own all-reduce over peer-mapped inboxes
-            progress(dist, "head-sharded leg, one-shot push all-reduce")
+            progress(dist, "head-sharded leg, one-shot push all-reduce (child processes)")
             try:
-                _, info, _ = tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=w,
-                                    collective="push")
-                extra["tp_push"] = info
+                info = push_leg_in_children(args, dist, device, t_legs + args.tp_leg_deadline - 15.0 - time.monotonic())
+                if info is not None:
+                    extra["tp_push"] = info
             except Exception as e:  # noqa: BLE001
                 extra["tp_push"] = {"error": f"{type(e).__name__}: {e}"[:500]}
         if not line_lock.acquire(blocking=False):

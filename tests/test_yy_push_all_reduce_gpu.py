@@ -216,3 +216,26 @@ def test_bench_default_multi_rank_run_reports_both_head_sharded_legs_or_gives_up
         assert d["tp_push"]["push_waits_given_up"] == 0 and d["tp_push"]["push_reduces_done"] > 0, d["tp_push"]
     else:
         assert "deadline" in d["tp"]["error"] and "deadline" in d["tp_push"]["error"]
+
+
+def test_bench_default_multi_rank_run_survives_a_rank_that_dies_in_the_push_leg(pkg):
+    """The push leg of a default multi-rank run is measured by child processes: when rank 1's child aborts
+    (what a GPU fault does to a process), the line still comes out once, from rank 0, with the replica
+    measurement and the backend leg in it and the push leg marked failed, and every parent rank exits 0."""
+    import json
+    import subprocess
+    import sys
+    from tests.test_all_reduce import ROOT, _free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--layers", "2", "--batch", "32", "--ctx", "256", "--dist-backend", "gloo",
+           "--no-c2", "--no-cpu-baseline", "--no-roofline", "--tp-leg-deadline", "90", "--rehearse-child-abort", "1"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["tp"]["tp"] == 2 and d["tp"]["value"] > 0, d["tp"]
+    assert "error" in d["tp_push"] and "child" in d["tp_push"]["error"], d["tp_push"]
