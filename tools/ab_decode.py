@@ -45,6 +45,10 @@ SHAPES = {
     "lognormal_bs128": dict(S=128, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
     "lognormal_bs64": dict(S=64, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
     "short256": dict(S=256, H=32, D=128, B=16, ctx=256, ragged=False),
+    "short128": dict(S=256, H=32, D=128, B=16, ctx=128, ragged=False),
+    "ctx512": dict(S=256, H=32, D=128, B=16, ctx=512, ragged=False),
+    "lognormal_1k": dict(S=256, H=32, D=128, B=16, ctx=1024, ragged="lognormal"),
+    "ragged512": dict(S=256, H=32, D=128, B=16, ctx=512, ragged=True),
     "bs64": dict(S=64, H=32, D=128, B=16, ctx=1024, ragged=False),
     "bs128": dict(S=128, H=32, D=128, B=16, ctx=1024, ragged=False),
 }
