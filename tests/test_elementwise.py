@@ -120,7 +120,7 @@ def test_operator_modules_like_the_reference_tests(pkg):
     g.manual_seed(0)
     for dtype in (torch.half, torch.bfloat16, torch.float):
         # rotary: 2145 tokens, 5 heads, q and k are slices of a fused qkv row (llama.py:119)
-        for head_size in (64, 80, 128, 256):
+        for head_size in (32, 64, 80, 96, 128, 160, 192, 256):  # test_pos_encoding.py:136
             T, H, mp = 2145, 5, 8192
             pos = torch.randint(0, mp, (T,), device=DEV, generator=g)
             qkv = torch.randn(T, 3 * H * head_size, dtype=dtype, device=DEV, generator=g)
@@ -137,7 +137,8 @@ def test_operator_modules_like_the_reference_tests(pkg):
                 want = torch.cat((x1 * c - x2 * s, x2 * c + x1 * s), dim=-1).view(T, H * head_size)
                 assert torch.allclose(got, want, atol=1e-3, rtol=1e-5), (dtype, head_size)
         # rms_norm
-        for T, hidden in ((7, 13), (128, 1024), (2048, 5120), (33, 8200)):
+        # the reference's grid (test_layernorm.py:47-49) and one row longer than the register-resident limit
+        for T, hidden in [(T, h) for T in (7, 128, 2048) for h in (13, 64, 1024, 5120)] + [(33, 8200)]:
             x = torch.randn(T, hidden, dtype=dtype, device=DEV, generator=g)
             w = (torch.rand(hidden, device=DEV, generator=g) * 2e-3 - 1e-3).to(dtype)
             out = torch.empty_like(x)
@@ -146,7 +147,7 @@ def test_operator_modules_like_the_reference_tests(pkg):
             want = w * (x * torch.rsqrt(var + 1e-6)).to(dtype)
             assert torch.allclose(out, want, atol=1e-3, rtol=1e-5), (dtype, T, hidden)
         # silu_and_mul
-        for T, d in ((7, 512), (83, 5120), (2048, 13824)):
+        for T, d in [(T, d) for T in (7, 83, 2048) for d in (512, 4096, 5120, 13824)]:  # test_activation.py:30-31
             x = torch.randn(T, 2 * d, dtype=dtype, device=DEV, generator=g)
             out = torch.empty(T, d, dtype=dtype, device=DEV)
             pkg.activation_ops.silu_and_mul(out, x)
