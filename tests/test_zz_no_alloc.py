@@ -31,10 +31,16 @@ def _both(pkg, case):
     nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size, B, mc)
     ws = torch.full((max(nbytes, 4) // 4,), float("nan"), dtype=torch.float32, device=dev) if nbytes else None
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
+    # torch's allocator counts every block and every segment it ever handed out: the counts cannot
+    # move unless something allocated (bytes in use can also DROP during the call, when Python
+    # happens to collect an earlier test's garbage)
+    def handed_out():
+        st = torch.cuda.memory_stats()
+        return st["allocation.all.allocated"], st["segment.all.allocated"]
+    before = handed_out()
     pkg._capi.single_query_cached_kv_attention_static(out_static, query, kc, vc, inp["scale"], bt, cl, B, mc)
     torch.cuda.synchronize()
-    assert (torch.cuda.memory_allocated(), torch.cuda.memory_reserved()) == before
+    assert handed_out() == before
     pkg._capi.single_query_cached_kv_attention_ws(out_ws, query, kc, vc, inp["scale"], bt, cl, B, mc, ws)
     torch.cuda.synchronize()
     ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(

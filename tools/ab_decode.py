@@ -45,6 +45,20 @@ SHAPES = {
     "lognormal_bs128": dict(S=128, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
     "lognormal_bs64": dict(S=64, H=32, D=128, B=16, ctx=2048, ragged="lognormal"),
     "short256": dict(S=256, H=32, D=128, B=16, ctx=256, ragged=False),
+    "bs2": dict(S=2, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs3": dict(S=3, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs4": dict(S=4, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs5": dict(S=5, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs6": dict(S=6, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs7": dict(S=7, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs4_512": dict(S=4, H=32, D=128, B=16, ctx=512, ragged=False),
+    "bs4_768": dict(S=4, H=32, D=128, B=16, ctx=768, ragged=False),
+    "bs6_512": dict(S=6, H=32, D=128, B=16, ctx=512, ragged=False),
+    "bs6_768": dict(S=6, H=32, D=128, B=16, ctx=768, ragged=False),
+    "bs4_ragged": dict(S=4, H=32, D=128, B=16, ctx=1024, ragged=True),
+    "bs6_ragged": dict(S=6, H=32, D=128, B=16, ctx=1024, ragged=True),
+    "c2_bs8": dict(S=8, H=12, D=64, B=16, ctx=1024, ragged=False),
+    "c2_bs20": dict(S=20, H=12, D=64, B=16, ctx=1024, ragged=False),
     "short128": dict(S=256, H=32, D=128, B=16, ctx=128, ragged=False),
     "ctx512": dict(S=256, H=32, D=128, B=16, ctx=512, ragged=False),
     "lognormal_1k": dict(S=256, H=32, D=128, B=16, ctx=1024, ragged="lognormal"),

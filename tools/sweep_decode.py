@@ -35,6 +35,10 @@ def configs():
         add(f"ns_ctx{ctx}", ctx=ctx)
     for S in (1, 4, 16, 64, 128):
         add(f"ns_bs{S}", S=S)
+    for S in (2, 6, 7, 8, 12):  # around the point where the rows alone fill the 256 CUs (32 heads: 8 sequences)
+        add(f"ns_bs{S}", S=S)
+    add("ns_bs6_ctx512", S=6, ctx=512)
+    add("c2_bs16", S=16, H=12, D=64)
     add("tiny_bs1_ctx64", S=1, ctx=64)
     add("tiny_bs4_ctx128", S=4, ctx=128)
     add("tiny_bs4_ctx512", S=4, ctx=512)

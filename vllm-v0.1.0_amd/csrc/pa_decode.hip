@@ -27,6 +27,7 @@
 // :240-251); the softmax denominator is (sum + 1e-6) as in the reference
 // (:213).  Offsets are 64-bit.
 #include <float.h>
+#include <limits.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -770,6 +771,7 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
 //    its sequences longest first, so that the launch ends on its shortest
 //    rows.  Ranks come from counting (keys are distinct): no sort needed for
 //    at most kMaxBalancedSeqs sequences.
+constexpr int kCUs = 256;  // compute units of the MI355X
 constexpr int kNoSplitBlocks = 1 << 24;
 constexpr int kPlanThreads = 1024;
 constexpr int kMaxBalancedSeqs = 1024;  // = kPlanThreads: one sequence per thread
@@ -784,6 +786,7 @@ struct PlanArgs {
   int split_pct;
   int num_heads;
   int resident_slots;   // workgroups of the decode kernel the GPU holds at a time
+  int keep_parts_min_blocks;  // a longest context of this many blocks keeps its partitions whatever the others are (few_rows_min_blocks)
   uint32_t* items;
   unsigned* counters;
   int2* row_table;      // null = no balanced order
@@ -836,8 +839,10 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
     }
     bool fits = (unsigned long long)scan[0] * 100ull * (unsigned)p.resident_slots <=
                 sums[0] * (unsigned long long)p.num_heads * (unsigned long long)p.split_pct;
-    // every row resident at once and the longest within a quarter of the mean: the rows end together anyway
+    // every row resident at once and the longest within a quarter of the mean: the rows end together
+    // anyway (unless the rows leave half the CUs idle and are long: see few_rows_min_blocks)
     fits = fits || ((unsigned long long)num_seqs * (unsigned)p.num_heads <= (unsigned)p.resident_slots &&
+                    scan[0] < (unsigned)p.keep_parts_min_blocks &&
                     (unsigned long long)scan[0] * (unsigned)num_seqs * 100ull <= sums[0] * 125ull);
     bpp = fits ? kNoSplitBlocks : p.blocks_per_part;
     __syncthreads();
@@ -1041,6 +1046,19 @@ static int resident_slots(int head_size) {
   return 256 * (head_size <= PA_DECODE_NW_HEAD64_MAXD && PA_DECODE_NW_HEAD64 == 8 ? 2 : 3);
 }
 
+// Equal-length rows that are all resident at once need no partitions to end together — unless
+// they leave at least half of the CUs idle and each is long: then the partitions are what fills
+// the chip.  Measured (32 heads x 128, equal lengths, item-list partitions of 256 tokens against
+// one workgroup per row): 3 sequences x 1024 tokens 20.4 -> 17.3 us, 4 x 1024 20.3 -> 17.8 us,
+// 4 x 768 17.8 -> 17.0 us; but 4 x 512 13.0 -> 14.4 us, 5 / 6 / 7 x 1024 21.4 -> 22.9 / 22.2 -> 24.6 /
+// 23.7 -> 27.9 us, 16 x 1024 at 12 heads x 64 14.0 -> 18.6 us.  Returns the longest context, in
+// blocks, from which on the partitions stay (INT_MAX: never).
+constexpr int kFewRowsMinElems = 768 * 128;  // tokens x head size
+static int few_rows_min_blocks(int64_t rows, int head_size, int block_size) {
+  if (rows * 2 > kCUs) return INT_MAX;
+  return (kFewRowsMinElems / head_size + block_size - 1) / block_size;
+}
+
 template <typename E, int D, int B>
 static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hipStream_t stream) {
   constexpr int NW = D <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves;
@@ -1058,6 +1076,7 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
     p.split_pct = split_pct();
     p.num_heads = a.num_heads;
     p.resident_slots = resident_slots(D);
+    p.keep_parts_min_blocks = few_rows_min_blocks((int64_t)a.num_seqs * a.num_heads, D, B);
     p.items = const_cast<uint32_t*>(a.items);
     p.counters = a.counters;
     p.row_table = const_cast<int2*>(a.row_table);
@@ -1339,7 +1358,8 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
       // slots and the merge launch are left out altogether.
       const int64_t longest = (max_context_len + block_size - 1) / block_size;
       const int64_t blocks = total_context_len / block_size;
-      const bool no_straggler = rows <= resident_slots(head_size) && longest * num_seqs * 100 <= blocks * 125;
+      const bool no_straggler = rows <= resident_slots(head_size) && longest < few_rows_min_blocks(rows, head_size, block_size) &&
+                                longest * num_seqs * 100 <= blocks * 125;
       if (no_straggler || longest * 100 * resident_slots(head_size) <= blocks * num_heads * split_pct()) {
         p.num_parts = 1;
         p.list = false;
