@@ -518,8 +518,11 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
       const int phys = table[b];
       e = phys;
 #if PA_DECODE_NT == 2
-      const bool shared = (table_prev != table && table_prev[b] == phys) ||
-                          (table_next != table && table_next[b] == phys);
+      // all three entries are fetched at once (table_prev / table_next point at this sequence's
+      // own table where there is no neighbour): a short-circuit here would put the second
+      // neighbour's load behind the first one's arrival, a whole trip to memory in every row's chain
+      const int before = table_prev[b], after = table_next[b];
+      const bool shared = ((table_prev != table) & (before == phys)) | ((table_next != table) & (after == phys));
       e |= shared ? (int)0x80000000 : 0;
 #endif
     }
