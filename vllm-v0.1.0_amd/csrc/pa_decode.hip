@@ -325,12 +325,11 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   int part = 0;
   if (MODE == kModeList) {
     // a workspace whose plan was never made, or made for other sizes
-    if (a.counters[0] != a.plan_tag) {
-      poison_output_row<E, D>(a);
-      return;
-    }
+    // (both words fetched before either is looked at: one trip to memory, not two)
+    const unsigned plan_stamp = a.counters[0];
     const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
-    if (n_items > a.list_slots) {  // more pairs than the caller's total_context_len allows for: it was not the sum
+    // n_items > list_slots: more pairs than the caller's total_context_len allows for — it was not the sum
+    if ((plan_stamp != a.plan_tag) | (n_items > a.list_slots)) {
       poison_output_row<E, D>(a);
       return;
     }
@@ -371,13 +370,21 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     const unsigned c = w / per_group, in = w - c * per_group;
     const unsigned hd = in / G;
     const unsigned i = c * G + (in - hd * G);
+    // The stamp and the entry are fetched together and looked at together: tested one after the
+    // other (and the stamp's two words with a short-circuit), each load waited for the previous
+    // one's answer — three trips to memory ahead of every row instead of one.
     const int2 stamp = a.row_table[8u * (unsigned)a.slots_per_xcd];
-    const int2 e = a.row_table[x * (unsigned)a.slots_per_xcd + i];
-    if ((unsigned)stamp.x != a.plan_tag || (unsigned)stamp.y != ~a.plan_tag) {  // not a plan for these sizes
-      poison_output_row<E, D>(a);
+    int2 e = a.row_table[x * (unsigned)a.slots_per_xcd + i];
+    // (the context length too: left to itself the compiler fetches that word behind the branch)
+    asm volatile("" : "+v"(e.x), "+v"(e.y));
+    e.x = __builtin_amdgcn_readfirstlane(e.x);
+    e.y = __builtin_amdgcn_readfirstlane(e.y);
+    const bool no_plan = ((unsigned)stamp.x != a.plan_tag) | ((unsigned)stamp.y != ~a.plan_tag);  // not a plan for these sizes
+    const bool empty_slot = (unsigned)e.x >= (unsigned)a.num_seqs;                                  // -1
+    if (no_plan | empty_slot) {
+      if (no_plan) poison_output_row<E, D>(a);
       return;
     }
-    if ((unsigned)e.x >= (unsigned)a.num_seqs) return;  // an empty slot (-1)
     head = (int)hd;
     seq = e.x;
     ctx = e.y;
@@ -1078,7 +1085,7 @@ static int few_rows_min_blocks(int64_t rows, int head_size, int block_size) {
 }
 
 template <typename E, int D, int B>
-static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hipStream_t stream) {
+static int launch(const DecodeArgs& a, bool plan_ready, hipStream_t stream) {
   constexpr int NW = D <= PA_DECODE_NW_HEAD64_MAXD ? PA_DECODE_NW_HEAD64 : kNumWaves;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
   // workgroups of the row pass: in the balanced order every XCD gets slots_per_xcd sequences' worth
@@ -1126,22 +1133,22 @@ static int launch(const DecodeArgs& a, int tokens_per_part, bool plan_ready, hip
 }
 
 template <typename E, int D>
-static int dispatch_block(int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
+static int dispatch_block(int B, const DecodeArgs& a, bool plan_ready, hipStream_t st) {
   switch (B) {
-    case 8: return launch<E, D, 8>(a, tpp, plan_ready, st);
-    case 16: return launch<E, D, 16>(a, tpp, plan_ready, st);
-    case 32: return launch<E, D, 32>(a, tpp, plan_ready, st);
+    case 8: return launch<E, D, 8>(a, plan_ready, st);
+    case 16: return launch<E, D, 16>(a, plan_ready, st);
+    case 32: return launch<E, D, 32>(a, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported block size: %d (supported: 8, 16, 32)", B);
   }
 }
 
 template <typename E>
-static int dispatch_head(int D, int B, const DecodeArgs& a, int tpp, bool plan_ready, hipStream_t st) {
+static int dispatch_head(int D, int B, const DecodeArgs& a, bool plan_ready, hipStream_t st) {
   switch (D) {
-    case 64: return dispatch_block<E, 64>(B, a, tpp, plan_ready, st);
-    case 80: return dispatch_block<E, 80>(B, a, tpp, plan_ready, st);
-    case 96: return dispatch_block<E, 96>(B, a, tpp, plan_ready, st);
-    case 128: return dispatch_block<E, 128>(B, a, tpp, plan_ready, st);
+    case 64: return dispatch_block<E, 64>(B, a, plan_ready, st);
+    case 80: return dispatch_block<E, 80>(B, a, plan_ready, st);
+    case 96: return dispatch_block<E, 96>(B, a, plan_ready, st);
+    case 128: return dispatch_block<E, 128>(B, a, plan_ready, st);
     default: return fail(PA_ERR_UNSUPPORTED, "unsupported head size: %d (supported: 64, 80, 96, 128)", D);
   }
 }
@@ -1428,12 +1435,11 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
       }
     }
   }
-  const int tokens_per_part = a.blocks_per_part * block_size;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (dtype) {
-    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
-    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
-    default: return dispatch_head<ElemBF16>(head_size, block_size, a, tokens_per_part, plan_mode == kPlanReady, st);
+    case PA_DTYPE_F32: return dispatch_head<ElemF32>(head_size, block_size, a, plan_mode == kPlanReady, st);
+    case PA_DTYPE_F16: return dispatch_head<ElemF16>(head_size, block_size, a, plan_mode == kPlanReady, st);
+    default: return dispatch_head<ElemBF16>(head_size, block_size, a, plan_mode == kPlanReady, st);
   }
 }
 
