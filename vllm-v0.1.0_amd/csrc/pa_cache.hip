@@ -130,6 +130,42 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
   }
 }
 
+// Vectors [lo, hi) of a block's value tile, read, given the new token's elements and written back
+// whole, U vectors in flight per lane.  Every load is unconditional (indices past the end are
+// clamped), the new elements' included: fetched only where needed, each of them waited for its own
+// trip to memory between one vector's store and the next (three trips more per workgroup).
+template <int ES>
+__device__ __forceinline__ void update_value_tile(u32x4* tile, const typename Word<ES>::type* new_row, int lo, int hi,
+                                                  int vpr, int piece, int lane_el) {
+  typedef typename Word<ES>::type elem_t;
+  constexpr int U = 4;  // vectors in flight per lane
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
+    u32x4 v[U];
+    elem_t nv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int ic = min(i0 + u * (int)blockDim.x, hi - 1);
+      v[u] = __builtin_nontemporal_load(tile + ic);
+      nv[u] = new_row[ic / vpr];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      if (i >= hi) continue;
+      const int r = i / vpr;
+      if (i - r * vpr == piece) {
+        if (ES == 4) {
+          v[u][lane_el] = (uint32_t)nv[u];
+        } else {
+          const int w = lane_el >> 1, sh = (lane_el & 1) * 16;
+          v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)nv[u] << sh);
+        }
+      }
+      __builtin_nontemporal_store(v[u], tile + i);
+    }
+  }
+}
+
 // ---- reshape_and_cache for decode-sized batches: whole value rows ------------------
 //
 // A decode step adds one token to the last block of every sequence.  In the
@@ -194,31 +230,7 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
   const int total = n * vpr;
   const int per = (total + gridDim.y - 1) / gridDim.y;
   const int lo = per * blockIdx.y, hi = min(lo + per, total);
-  constexpr int U = 4;  // vectors in flight per lane
-  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
-    u32x4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * blockDim.x;
-      if (i < hi) v[u] = __builtin_nontemporal_load(tile + i);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * blockDim.x;
-      if (i >= hi) continue;
-      const int r = i / vpr;
-      if (i - r * vpr == piece) {
-        const elem_t val = reinterpret_cast<const elem_t*>(vrow)[r];
-        if (ES == 4) {
-          v[u][lane_el] = (uint32_t)val;
-        } else {
-          const int w = lane_el >> 1, sh = (lane_el & 1) * 16;
-          v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)val << sh);
-        }
-      }
-      __builtin_nontemporal_store(v[u], tile + i);
-    }
-  }
+  update_value_tile<ES>(tile, reinterpret_cast<const elem_t*>(vrow), lo, hi, vpr, piece, lane_el);
 }
 
 // ---- rotary embedding + reshape_and_cache in one pass (decode-sized batches) ---------
@@ -319,31 +331,7 @@ pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ q
   const int total = n * vpr;
   const int per = (total + gridDim.y - 1) / gridDim.y;
   const int lo = per * blockIdx.y, hi = min(lo + per, total);
-  constexpr int U = 4;
-  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
-    u32x4 v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * blockDim.x;
-      if (i < hi) v[u] = __builtin_nontemporal_load(tile + i);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int i = i0 + u * blockDim.x;
-      if (i >= hi) continue;
-      const int r = i / vpr;
-      if (i - r * vpr == piece) {
-        const elem_t val = reinterpret_cast<const elem_t*>(vrow)[r];
-        if (ES == 4) {
-          v[u][lane_el] = (uint32_t)val;
-        } else {
-          const int w = lane_el >> 1, sh = (lane_el & 1) * 16;
-          v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)val << sh);
-        }
-      }
-      __builtin_nontemporal_store(v[u], tile + i);
-    }
-  }
+  update_value_tile<ES>(tile, reinterpret_cast<const elem_t*>(vrow), lo, hi, vpr, piece, lane_el);
 }
 
 // ---- reshape_and_cache / gather_cached_kv for prompt-sized batches --------------
