@@ -190,7 +190,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 //   blocks_per_part KV blocks and writes its un-normalised (max, sum,
 //   accumulator) triple to a workspace; pa_decode_merge_kernel combines the
 //   partitions.  Every sequence gets the same number of partitions (the empty
-//   ones exit at once): for few sequences, where the chip is otherwise idle.
+//   ones leave the neutral element and exit): for few sequences, where the chip
+//   is otherwise idle.
 // kModeList : for big batches with long contexts.  Partitions of a fixed
 //   length, as many as each sequence needs (at most four).  Every row's first
 //   partition has a workgroup of its own, as in kModeRows;
