@@ -188,6 +188,24 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def describe(self, torch):
+        """Who took part, for a reader of the line: the backend, the ranks, the GPUs they sat on (gathered
+        over the group, so a rank that saw another device shows) and the collective library's version."""
+        info = {"backend": self.dist.get_backend() if self.active else None, "world": self.world}
+        mine = {"rank": self.rank, "device": torch.cuda.current_device() if torch.cuda.is_available() else None,
+                "visible": torch.cuda.device_count() if torch.cuda.is_available() else 0}
+        seen = [None] * self.world
+        if self.active:
+            self.dist.all_gather_object(seen, mine)
+        else:
+            seen = [mine]
+        info["devices_seen"] = seen
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            info["rccl_version"] = f"unavailable ({type(e).__name__})"
+        return info
+
     def close(self):
         if self.active:
             self.dist.destroy_process_group()
@@ -419,8 +437,10 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
     push = None
     if not emulate and (collective or args.tp_collective) == "push" and tp > 1:
         from vllm_amd.worker import PushAllReduce
-        push = PushAllReduce(S * hidden * w.es, device=device)  # handles exchanged over the process group
-        push.self_test()  # all ranks agree that the peers' memory is reachable, or all raise
+        # handles exchanged over the process group; set-up ends with the collective self-test (both forms, a
+        # small and a multi-MiB message): all ranks agree that the peers' memory is reachable and ordered, or
+        # all raise.  A bench leg can afford a shorter wait for a dead peer than a serving process.
+        push = PushAllReduce(S * hidden * w.es, device=device, wait_seconds=10.0)
         reduce_fn = push
     elif not emulate and args.dist_backend != "nccl":
         # rehearsal on a box without one GPU per rank: the sum goes through host memory (the
@@ -452,11 +472,19 @@ def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_c
     if args.abort_before_timing:
         os.abort()  # rehearsal of a rank that dies in the leg
     elapsed = timed_region(dist, device, step, args.steps, args.warmup, torch.cuda.synchronize)
+    # a reduce that gave up on a peer left NaNs: no number from such a run, and all ranks leave the leg together
+    failure = None
+    try:
+        launcher.check()
+    except RuntimeError as e:
+        failure = str(e)
+    if (dist.sum_float(1.0 if failure else 0.0, device) if not emulate else bool(failure)):
+        raise RuntimeError(failure or "another rank's all-reduce gave up waiting for a peer")
     progress(dist, f"tp leg timed: {elapsed * 1e3 / args.steps:.3f} ms")
     coll = ("one-shot push" if push is not None else "stand-in" if emulate else
             "RCCL" if args.dist_backend == "nccl" else f"{args.dist_backend} (host-staged)")
     info = {
-        "tp": tp, "heads_per_rank": Hl, "layers": L, "scaling": "strong",
+        "tp": tp, "heads_per_rank": Hl, "layers": L, "scaling": "strong", **({} if emulate else dist.describe(torch)),
         "value": S * args.steps / elapsed, "unit": "tokens/s", "ms_per_step": elapsed * 1e3 / args.steps,
         "step": "per layer: reshape_and_cache + single_query_cached_kv_attention on the local heads, row-parallel "
                 "o_proj matmul [batch, heads/tp * head_size] x [.., hidden] into the all-reduce buffer, "
@@ -682,6 +710,7 @@ def main(argv=None):
                 "context_len": CTX, "layers": info["layers"], "sharding": "heads/tp", "parallelism": f"tp{n_tp}",
             }
             extra = {"tp": {k: v for k, v in info.items() if k not in ("value", "unit", "ms_per_step", "step")}}
+            extra["ranks"] = {k: info[k] for k in ("backend", "world", "devices_seen", "rccl_version") if k in info}
             print(json.dumps(result_line(args, dist.world, elapsed, float(S * args.steps), "tokens/s", config, extra,
                                          metric_text(args, model_name, n_tp), "strong")))
         dist.close()
@@ -732,6 +761,8 @@ def main(argv=None):
     progress(dist, f"replica step timed: {elapsed * 1e3 / args.steps:.3f} ms")
 
     extra = {}
+    if dist.active:
+        extra["ranks"] = dist.describe(torch)  # collective: every rank calls it
     # ---- roofline of the dominant kernel (decode attention) ------------------------------------
     if not args.no_roofline and dist.rank == 0:
         roof = decode_roofline(torch, attention_ops, cache_ops, w, workspace, max(2 * L, 20))
@@ -802,6 +833,9 @@ def main(argv=None):
                 for leg in ("tp", "tp_push"):
                     if leg == "tp" or args.tp_collective != "push":
                         extra.setdefault(leg, {"error": f"did not finish within the {args.tp_leg_deadline:.0f} s deadline of the extra legs"})
+                # every rank leaves with status 0 (a rank failing first would have the launcher end rank 0
+                # before its line is out): the line itself says that a leg hung
+                extra["extra_legs_deadline_expired"] = True
                 emit()
             if CHILD is not None:
                 CHILD.kill()

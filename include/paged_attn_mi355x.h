@@ -414,12 +414,22 @@ int pa_silu_and_mul(
  *                    must issue the same sequence of reduces.  Reduces of one
  *                    communicator must not overlap in time (one stream, or
  *                    event-ordered).  A rank whose peers do not arrive within
- *                    two seconds gives up the wait, fills its result with NaN
- *                    and counts a timeout; the communicator is broken from
- *                    then on (later reduces on it wait for nobody, return NaN
- *                    and keep counting: a dead peer costs one bounded wait,
- *                    not one per reduce) and must be replaced.
- *   pa_comm_status   synchronous read-back: reduces completed, timeouts.
+ *                    the wait budget gives up the wait, fills its result with
+ *                    NaN and counts a timeout; the communicator is broken from
+ *                    then on and must be replaced: later reduces on it do not
+ *                    wait any more — one whose peers' flags are already there
+ *                    still returns the sum, every other one NaN and another
+ *                    count (a dead peer costs one bounded wait, not one per
+ *                    reduce).  The result is not symmetric: the rank that gave
+ *                    up holds NaN while its peers may hold a valid sum.
+ *   pa_comm_set_wait_budget  how long a reduce waits for its peers, in seconds
+ *                    (default 30; applies to launches made, or captured, after
+ *                    the call).  It has to cover the longest stall a healthy
+ *                    rank can have between two reduces (graph capture, a code
+ *                    object loading, a profiler attaching).
+ *   pa_comm_status   synchronous read-back: reduces completed, timeouts.  A
+ *                    caller checks it where it synchronises anyway (the end of
+ *                    a step) and stops on a timeout rather than use the NaNs.
  */
 #define PA_COMM_HANDLE_BYTES 128
 
@@ -445,6 +455,7 @@ int pa_comm_connect(pa_comm* comm, const unsigned char* all_handles);
 int pa_comm_connect_local(pa_comm* comm, pa_comm* const* all_comms);
 int pa_comm_all_reduce(pa_comm* comm, void* data, size_t count, int dtype,
                        int algorithm, void* stream);
+int pa_comm_set_wait_budget(pa_comm* comm, double seconds);
 int pa_comm_status(pa_comm* comm, uint32_t* reduces_done, uint32_t* timeouts);
 int pa_comm_destroy(pa_comm* comm);
 

@@ -26,13 +26,13 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_ranks(source: str, nproc: int, timeout: int = 300, env_extra=None):
+def _run_ranks(source: str, nproc: int, timeout: int = 300, env_extra=None, env_replace=None):
     with tempfile.NamedTemporaryFile("w", suffix="_tp_worker.py", delete=False) as f:
         f.write(source)
         path = f.name
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), path]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ if env_replace is None else env_replace, OMP_NUM_THREADS="1")
     env.update(env_extra or {})
     try:
         return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -264,22 +264,65 @@ _RCCL_WORKER = textwrap.dedent("""
     import torch, torch.distributed as dist
     import __graft_entry__
     __graft_entry__.load_package()
-    from vllm_amd.worker import GraphAllReduce
+    from vllm_amd.worker import GraphAllReduce, PushAllReduce
     rank = int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(rank)
     dist.init_process_group(backend="nccl")
     world = dist.get_world_size()
     dev = torch.device("cuda", rank)
-    launcher = GraphAllReduce(64, 1024, torch.float16, device=dev)
+    hidden = 1024
+
+    def partial_sums(n, seed):
+        # every rank can compute every rank's partial sums: the expected total needs no second collective
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        return [torch.randn(n, hidden, generator=g).half() for _ in range(world)]
+
+    def drive(launcher, exact, label):
+        busy = torch.randn(1024, 1024, device=dev)
+        # 8 is pre-captured; 32 and 48 are captured on first use, in the middle of a step, with LIVE partial
+        # sums in the buffer (the warm-up reduce of the capture must not eat them); every count comes round
+        # on both buffers of the ring, and each graph is replayed with fresh data
+        for step, n in enumerate((8, 32, 8, 32, 48, 48, 8, 32, 64)):
+            parts = partial_sums(n, 100 + step)
+            total = parts[0].float()
+            for p in parts[1:]:
+                total = total + p.float()
+            for _ in range(2):
+                busy = busy @ busy * 1e-3            # the producer of the partial sums sits behind queued work
+            buf = launcher.next_buffer(n)
+            buf.copy_(parts[rank].to(dev), non_blocking=True)
+            pending = launcher.launch_async(buf)
+            for _ in range(2):
+                busy = busy @ busy * 1e-3            # work that overlaps the reduce
+            y = pending.wait()
+            torch.cuda.synchronize()
+            if exact:   # rank-ordered fp32 sum rounded once: the push all-reduce's contract
+                assert torch.equal(y.cpu(), total.half()), (label, rank, step, n)
+            else:       # RCCL chooses its own order and intermediate precision
+                assert torch.allclose(y.cpu().float(), total, atol=2e-2, rtol=2e-3), (label, rank, step, n)
+        launcher.check()
+
+    # 1. the backend's collective (RCCL) captured and replayed on the side stream
+    launcher = GraphAllReduce(64, hidden, torch.float16, device=dev)
+    assert not launcher.disable_graph
     launcher.precapture([8])
-    total = sum(range(1, world + 1))
-    for n in (8, 32, 8, 32):  # 32: captured on first use, in the middle of a step
-        buf = launcher.next_buffer(n)
-        buf.fill_(rank + 1.0)
-        y = launcher.launch_async(buf).wait()
-        assert torch.all(y == float(total)), (rank, n)
+    assert sorted(launcher.graphs) == [(0, 8), (1, 8)]
+    drive(launcher, False, "rccl graph")
+    assert {k[1] for k in launcher.graphs} == {8, 32, 48, 64}
+    # 2. the same without graphs: direct calls on the side stream (bench.py's default for its RCCL leg)
+    drive(GraphAllReduce(64, hidden, torch.float16, device=dev, disable_graph=True), False, "rccl direct")
+    # 3. the one-shot push all-reduce between two GPUs: peers' memory through IPC over xGMI.  Set-up runs the
+    # collective self-test (both forms, small and multi-MiB messages); then the launcher, graphs on live data.
+    push = PushAllReduce(4 << 20, device=dev, wait_seconds=20.0)
+    assert push.self_test_reduces == 8
+    launcher = GraphAllReduce(64, hidden, torch.float16, device=dev, reduce_fn=push)
+    launcher.precapture([8])
+    drive(launcher, True, "push graph")
+    done, gave_up = push.status()
+    assert gave_up == 0 and done >= 8 + 9, (done, gave_up)
     torch.cuda.synchronize()
     dist.barrier()
+    push.close()
     dist.destroy_process_group()
     if rank == 0:
         print("RCCL_GRAPH_OK")
@@ -288,8 +331,9 @@ _RCCL_WORKER = textwrap.dedent("""
 
 @pytest.mark.gpu
 def test_graph_replay_over_rccl_two_ranks():
-    """The real collective, captured and replayed on the side stream, on first
-    use and pre-captured.  Needs two GPUs (one process each)."""
+    """The real collective, captured and replayed on the side stream — pre-captured and captured on first
+    use with live partial sums in the buffer — and issued directly; then this package's push all-reduce
+    between the two GPUs, self-test included.  Needs two GPUs (one process each)."""
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs; the single-GPU test above covers the launcher's stream and graph machinery")

@@ -73,13 +73,15 @@ def test_ranks_on_one_gpu_by_pointer(pkg, world, algorithm):
 
 
 def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
-    """Rank 1 of two never launches: rank 0's first reduce gives up after the two-second bound, counts
-    it and returns NaNs, and every later reduce of that communicator does the same without waiting."""
+    """Rank 1 of two never launches: rank 0's first reduce gives up after the wait budget (two seconds
+    here; the serving default is 30), counts it and returns NaNs, every later reduce of that communicator
+    does the same without waiting, and check() — what the launcher calls at the end of a step — raises."""
     import time
     import torch
-    from vllm_amd.worker import PushAllReduce
+    from vllm_amd.worker import GraphAllReduce, PushAllReduce
     dev = torch.device("cuda:0")
-    ranks = PushAllReduce.local_ranks(2, 1 << 16)
+    assert PushAllReduce.DEFAULT_WAIT_SECONDS >= 30.0
+    ranks = PushAllReduce.local_ranks(2, 1 << 16, wait_seconds=2.0)
     try:
         x = torch.ones(4096, dtype=torch.float16, device=dev)
         torch.cuda.synchronize()
@@ -101,6 +103,14 @@ def test_a_peer_that_never_arrives_costs_one_bounded_wait(pkg):
         assert done2 == 21 and gave_up2 > gave_up, (done2, gave_up2)
         assert later < 0.5, later
         assert bool(torch.isnan(x).all())
+        with pytest.raises(RuntimeError, match="gave up"):
+            ranks[0].check()
+        launcher = GraphAllReduce(8, 512, torch.float16, device=dev, reduce_fn=ranks[0], disable_graph=True)
+        with pytest.raises(RuntimeError, match="gave up"):
+            launcher.check()
+        ranks[1].check()  # the rank that never reduced has nothing to report
+        with pytest.raises(pkg._capi.PagedAttnError, match="budget"):
+            pkg._capi.comm_set_wait_budget(ranks[0]._comm, 0.0)
     finally:
         for r in ranks:
             r.close()
@@ -153,7 +163,10 @@ _IPC_WORKER = textwrap.dedent("""
     # 16 and 40 tokens met buffer 0 of the ring, 64 buffer 1: three graphs, each captured after one warm-up reduce
     assert sorted(launcher.graphs) == [(0, 16), (0, 40), (1, 64)], sorted(launcher.graphs)
     done, timeouts = reduce.status()
-    assert (done, timeouts) == (bare + 7 + 3, 0), (rank, done, timeouts)
+    # set-up ran the self-test: both forms on a small and on a 1 MiB message, twice each
+    assert reduce.self_test_reduces == 8, reduce.self_test_reduces
+    assert (done, timeouts) == (reduce.self_test_reduces + bare + 7 + 3, 0), (rank, done, timeouts)
+    launcher.check()
     dist.barrier()
     reduce.close()
     print(f"rank {rank} ok", flush=True)
@@ -166,6 +179,21 @@ def test_ranks_in_processes_of_their_own_through_ipc(pkg, world):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     for r in range(world):
         assert f"rank {r} ok" in res.stdout
+
+
+def test_ipc_set_up_without_the_dmabuf_variable_works_or_names_it(pkg):
+    """The ranks' processes map each other's memory through HIP IPC handles.  On hosts whose driver only
+    offers dmabuf IPC that needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment; elsewhere it does not.
+    Without the variable, set-up either works (and the reduces are right) or raises on EVERY rank with a
+    message that names the variable — never a hang, never one rank failing alone."""
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    res = _run_ranks(_IPC_WORKER, 2, timeout=240, env_replace=env)
+    if res.returncode == 0:
+        assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+    else:
+        text = res.stdout + res.stderr
+        assert text.count("HSA_ENABLE_IPC_MODE_LEGACY") >= 2, text[-4000:]
+        assert "one-shot all-reduce set-up failed" in text, text[-4000:]
 
 
 def test_bench_head_sharded_step_with_the_push_collective_two_ranks_on_one_gpu(pkg):

@@ -46,6 +46,7 @@ EXPORTS = (
     "pa_comm_connect",
     "pa_comm_connect_local",
     "pa_comm_all_reduce",
+    "pa_comm_set_wait_budget",
     "pa_comm_status",
     "pa_comm_destroy",
 )
@@ -114,6 +115,8 @@ def _load() -> ctypes.CDLL:
     lib.pa_comm_connect_local.restype = i32
     lib.pa_comm_all_reduce.argtypes = [vp, vp, ctypes.c_size_t, i32, i32, vp]
     lib.pa_comm_all_reduce.restype = i32
+    lib.pa_comm_set_wait_budget.argtypes = [vp, ctypes.c_double]
+    lib.pa_comm_set_wait_budget.restype = i32
     lib.pa_comm_status.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     lib.pa_comm_status.restype = i32
     lib.pa_comm_destroy.argtypes = [vp]
@@ -358,6 +361,11 @@ def comm_all_reduce(comm, tensor, stream=None, algorithm: int = COMM_AUTO) -> No
     """In-place sum of a contiguous tensor over the communicator's ranks, on `stream` (default: torch's current)."""
     check(lib.pa_comm_all_reduce(comm, tensor.data_ptr(), tensor.numel(), dtype_code(tensor.dtype), int(algorithm),
                                  _stream_handle(stream)))
+
+
+def comm_set_wait_budget(comm, seconds: float) -> None:
+    """How long a reduce launched (or captured) from now on waits for its peers before it gives up."""
+    check(lib.pa_comm_set_wait_budget(comm, float(seconds)))
 
 
 def comm_status(comm):

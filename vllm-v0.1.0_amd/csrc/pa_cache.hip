@@ -134,20 +134,27 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
 // whole, U vectors in flight per lane.  Every load is unconditional (indices past the end are
 // clamped), the new elements' included: fetched only where needed, each of them waited for its own
 // trip to memory between one vector's store and the next (three trips more per workgroup).
-template <int ES>
-__device__ __forceinline__ void update_value_tile(u32x4* tile, const typename Word<ES>::type* new_row, int lo, int hi,
-                                                  int vpr, int piece, int lane_el) {
+// The first pass is split in two — load_first() / finish() — so that a kernel can put the loads in
+// flight as soon as it knows the block, and do whatever else it has to wait for (the scan of
+// slot_mapping for a second token in the block, the key rows, a rotation) under them.
+template <int ES, int U>
+struct ValueTileUpdate {
   typedef typename Word<ES>::type elem_t;
-  constexpr int U = 4;  // vectors in flight per lane
-  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += U * blockDim.x) {
-    u32x4 v[U];
-    elem_t nv[U];
+  u32x4* tile;
+  const elem_t* new_row;
+  int lo, hi, vpr, piece, lane_el;
+  u32x4 v[U];
+  elem_t nv[U];
+
+  __device__ __forceinline__ void load(int i0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int ic = min(i0 + u * (int)blockDim.x, hi - 1);
       v[u] = __builtin_nontemporal_load(tile + ic);
       nv[u] = new_row[ic / vpr];
     }
+  }
+  __device__ __forceinline__ void patch_and_store(int i0) {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int i = i0 + u * blockDim.x;
@@ -164,7 +171,19 @@ __device__ __forceinline__ void update_value_tile(u32x4* tile, const typename Wo
       __builtin_nontemporal_store(v[u], tile + i);
     }
   }
-}
+  // lo < hi is the caller's business (an empty slice loads nothing it may not: index hi - 1 >= lo)
+  __device__ __forceinline__ void load_first() {
+    if (lo < hi) load(lo + (int)threadIdx.x);
+  }
+  __device__ __forceinline__ void finish() {
+    int i0 = lo + (int)threadIdx.x;
+    if (lo < hi) patch_and_store(i0);
+    for (i0 += U * (int)blockDim.x; i0 - (int)threadIdx.x < hi; i0 += U * (int)blockDim.x) {
+      load(i0);
+      patch_and_store(i0);
+    }
+  }
+};
 
 // ---- reshape_and_cache for decode-sized batches: whole value rows ------------------
 //
@@ -183,7 +202,7 @@ __device__ __forceinline__ void update_value_tile(u32x4* tile, const typename Wo
 // goes to the same block (tokens of one prompt do): every workgroup checks the
 // whole slot_mapping first and falls back to element stores otherwise, which is
 // also what a batch with a repeated slot gets.
-template <int ES>
+template <int ES, int U>
 __global__ void __launch_bounds__(256)
 pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ value, char* __restrict__ key_cache,
                        char* __restrict__ value_cache, const int* __restrict__ slot_mapping, const int num_tokens,
@@ -196,6 +215,35 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
   if (slot < 0) return;
   const int64_t blk = slot / block_size;
   const int off = slot % block_size;
+  const int n = num_heads * head_size;
+  const char* krow = key + (int64_t)token * key_stride_bytes;
+  const char* vrow = value + (int64_t)token * value_stride_bytes;
+  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
+
+  // values: the tile is n rows of block_size elements = n * vpr vectors; the
+  // new element of row r sits in vector `piece` of the row, at element `lane_el`.
+  // Its loads go out first: reading the tile is harmless even if the scan below finds a second
+  // token in the block, and everything else this workgroup waits for arrives under them.
+  ValueTileUpdate<ES, U> vt;
+  vt.vpr = block_size / X;  // vectors per row (>= 1: checked by the host)
+  vt.piece = off / X;
+  vt.lane_el = off % X;
+  vt.tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
+  vt.new_row = reinterpret_cast<const elem_t*>(vrow);
+  const int total = n * vt.vpr;
+  const int per = (total + gridDim.y - 1) / gridDim.y;
+  vt.lo = per * blockIdx.y;
+  vt.hi = min(vt.lo + per, total);
+  vt.load_first();
+
+  // keys: one 16-byte vector of the token row = one innermost [x] run of the key cache
+  const int nvec = n / X;
+  const int ndx = head_size / X;
+  const int kstep = gridDim.y * blockDim.x;
+  const int k0 = blockIdx.y * blockDim.x + threadIdx.x;
+  u32x4 kfirst = {0u, 0u, 0u, 0u};
+  if (k0 < nvec) kfirst = *reinterpret_cast<const u32x4*>(krow + (int64_t)k0 * 16);
+
   int clash = 0;
   for (int t = threadIdx.x; t < num_tokens; t += blockDim.x) {
     const int s = slot_mapping[t];
@@ -203,18 +251,12 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
   }
   clash = __syncthreads_or(clash);
 
-  const int n = num_heads * head_size;
-  const char* krow = key + (int64_t)token * key_stride_bytes;
-  const char* vrow = value + (int64_t)token * value_stride_bytes;
-  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
-  const int nvec = n / X;
-  const int ndx = head_size / X;
-  // keys: one 16-byte vector of the token row = one innermost [x] run of the key cache
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < nvec; i += gridDim.y * blockDim.x) {
+  for (int i = k0; i < nvec; i += kstep) {
     const int h = i / ndx;
     const int dx = i - h * ndx;
     const int64_t kc_el = cache_block + (((int64_t)h * ndx + dx) * block_size + off) * X;
-    store_cache(reinterpret_cast<u32x4*>(key_cache + kc_el * ES), *reinterpret_cast<const u32x4*>(krow + (int64_t)i * 16));
+    const u32x4 kv = i == k0 ? kfirst : *reinterpret_cast<const u32x4*>(krow + (int64_t)i * 16);
+    store_cache(reinterpret_cast<u32x4*>(key_cache + kc_el * ES), kv);
   }
   if (clash) {
     for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x)
@@ -222,15 +264,7 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
           reinterpret_cast<const elem_t*>(vrow)[i];
     return;
   }
-  // values: the tile is n rows of block_size elements = n * vpr vectors; the
-  // new element of row r sits in vector `piece` of the row, at element `lane_el`
-  const int vpr = block_size / X;  // vectors per row (>= 1: checked by the host)
-  const int piece = off / X, lane_el = off % X;
-  u32x4* tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
-  const int total = n * vpr;
-  const int per = (total + gridDim.y - 1) / gridDim.y;
-  const int lo = per * blockIdx.y, hi = min(lo + per, total);
-  update_value_tile<ES>(tile, reinterpret_cast<const elem_t*>(vrow), lo, hi, vpr, piece, lane_el);
+  vt.finish();
 }
 
 // ---- rotary embedding + reshape_and_cache in one pass (decode-sized batches) ---------
@@ -247,7 +281,7 @@ pa_token_append_kernel(const char* __restrict__ key, const char* __restrict__ va
 // Per head the D / X vectors of a row are: embed / X "x" vectors, their embed / X partners
 // ("y", rot_dim / 2 elements further on), and (D - rot_dim) / X vectors the rotation leaves
 // alone.  One work item = an (x, y) pair, or one untouched vector.
-template <typename T>
+template <typename T, int U>
 __global__ void __launch_bounds__(256)
 pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ query, T* __restrict__ key,
                         const T* __restrict__ value, const T* __restrict__ cos_sin_cache, char* __restrict__ key_cache,
@@ -262,6 +296,29 @@ pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ q
   const int slot = slot_mapping[token];
   const int64_t blk = slot >= 0 ? slot / block_size : 0;
   const int off = slot >= 0 ? slot % block_size : 0;
+  const int n = num_heads * head_size;
+  T* qrow = query + (int64_t)token * query_stride;
+  T* krow = key + (int64_t)token * key_stride;
+  const T* vrow = value + (int64_t)token * value_stride;
+  const T* cs = cos_sin_cache + positions[token] * rot_dim;
+  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
+
+  // values: the block's tile is read first (see pa_token_append_kernel); the scan and the rotation
+  // run under its loads
+  ValueTileUpdate<ES, U> vt;
+  vt.vpr = block_size / X;
+  vt.piece = off / X;
+  vt.lane_el = off % X;
+  vt.tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
+  vt.new_row = reinterpret_cast<const elem_t*>(vrow);
+  {
+    const int total = n * vt.vpr;
+    const int per = (total + gridDim.y - 1) / gridDim.y;
+    vt.lo = per * blockIdx.y;
+    vt.hi = min(vt.lo + per, total);
+  }
+  if (slot >= 0) vt.load_first();
+
   int clash = 0;
   if (slot >= 0) {
     for (int t = threadIdx.x; t < num_tokens; t += blockDim.x) {
@@ -270,13 +327,6 @@ pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ q
     }
   }
   clash = __syncthreads_or(clash);
-
-  const int n = num_heads * head_size;
-  T* qrow = query + (int64_t)token * query_stride;
-  T* krow = key + (int64_t)token * key_stride;
-  const T* vrow = value + (int64_t)token * value_stride;
-  const T* cs = cos_sin_cache + positions[token] * rot_dim;
-  const int64_t cache_block = blk * (int64_t)n * block_size;  // elements
   const int embed = rot_dim / 2;
   const int ndx = head_size / X;   // vectors per head
   const int epx = embed / X;       // (x, y) pairs per head
@@ -324,14 +374,8 @@ pa_rotary_append_kernel(const int64_t* __restrict__ positions, T* __restrict__ q
           reinterpret_cast<const elem_t*>(vrow)[i];
     return;
   }
-  // values: read the block's tile, put the new elements in, write it back (see pa_token_append_kernel)
-  const int vpr = block_size / X;
-  const int piece = off / X, lane_el = off % X;
-  u32x4* tile = reinterpret_cast<u32x4*>(value_cache + cache_block * ES);
-  const int total = n * vpr;
-  const int per = (total + gridDim.y - 1) / gridDim.y;
-  const int lo = per * blockIdx.y, hi = min(lo + per, total);
-  update_value_tile<ES>(tile, reinterpret_cast<const elem_t*>(vrow), lo, hi, vpr, piece, lane_el);
+  // values: put the new elements into the tile and write it back (see pa_token_append_kernel)
+  vt.finish();
 }
 
 // ---- reshape_and_cache / gather_cached_kv for prompt-sized batches --------------
@@ -480,6 +524,33 @@ pa_token_runs_kernel(char* __restrict__ key, char* __restrict__ value, char* __r
 #define PA_CACHE_RUNS_MIN_TOKENS 512
 #endif
 
+// Launch shape of the whole-tile value update (pa_token_append_kernel, pa_rotary_append_kernel):
+// `slices` workgroups per token, each reading and rewriting its share of the block's value tile
+// with `in_flight` 16-byte vectors per lane in the air.
+struct AppendShape {
+  int slices;
+  int in_flight;
+};
+#ifndef PA_CACHE_APPEND_IN_FLIGHT
+#define PA_CACHE_APPEND_IN_FLIGHT 4
+#endif
+#ifndef PA_CACHE_APPEND_WORKGROUPS
+#define PA_CACHE_APPEND_WORKGROUPS 2048
+#endif
+static AppendShape append_shape(int num_tokens, int tile_vecs) {
+  static const int in_flight = tuning_int("PA_CACHE_APPEND_IN_FLIGHT", PA_CACHE_APPEND_IN_FLIGHT);  // 4, 8 or 16
+  static const int target = tuning_int("PA_CACHE_APPEND_WORKGROUPS", PA_CACHE_APPEND_WORKGROUPS);
+  AppendShape sh;
+  sh.in_flight = in_flight == 16 ? 16 : in_flight == 8 ? 8 : 4;
+  // about `target` workgroups in all; a slice is at least one pass of in_flight vectors per lane
+  int sl = (target + num_tokens - 1) / num_tokens;
+  const int most = (tile_vecs + sh.in_flight * 256 - 1) / (sh.in_flight * 256);
+  if (sl > most) sl = most;
+  if (sl < 1) sl = 1;
+  sh.slices = sl;
+  return sh;
+}
+
 template <bool GATHER>
 static int token_cache_op(const char* what, void* key, void* value, void* key_cache, void* value_cache,
                           const int32_t* slot_mapping, int num_tokens, int num_heads, int head_size,
@@ -530,18 +601,17 @@ static int token_cache_op(const char* what, void* key, void* value, void* key_ca
   static const int append_rows = tuning_int("PA_CACHE_APPEND_ROWS", 1);  // tuning builds: 0 = element stores for the values
   if (!GATHER && append_rows != 0 && vec && num_tokens >= kAppendMinTokens && aligned16(value_cache) &&
       (block_size * es) % 16 == 0 && (head_size * es) % 16 == 0) {
-    // ~8 workgroups per CU; a slice is at least one pass of 4 vectors per lane
     const int tile_vecs = num_heads * head_size * (block_size / x);
-    int sl = (2048 + num_tokens - 1) / num_tokens;
-    const int most = (tile_vecs + 4 * 256 - 1) / (4 * 256);
-    if (sl > most) sl = most;
-    if (sl < 1) sl = 1;
-    if (es == 2)
-      hipLaunchKernelGGL((pa_token_append_kernel<2>), dim3(num_tokens, sl), dim3(256), 0, st, k, v, kc, vc, slot_mapping,
-                         num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es);
-    else
-      hipLaunchKernelGGL((pa_token_append_kernel<4>), dim3(num_tokens, sl), dim3(256), 0, st, k, v, kc, vc, slot_mapping,
-                         num_tokens, num_heads, head_size, block_size, key_stride * es, value_stride * es);
+    const AppendShape sh = append_shape(num_tokens, tile_vecs);
+#define PA_LAUNCH_APPEND(ES, U)                                                                                     \
+  hipLaunchKernelGGL((pa_token_append_kernel<ES, U>), dim3(num_tokens, sh.slices), dim3(256), 0, st, k, v, kc, vc, \
+                     slot_mapping, num_tokens, num_heads, head_size, block_size, key_stride * ES, value_stride * ES)
+    if (es == 2) {
+      if (sh.in_flight == 16) PA_LAUNCH_APPEND(2, 16); else if (sh.in_flight == 8) PA_LAUNCH_APPEND(2, 8); else PA_LAUNCH_APPEND(2, 4);
+    } else {
+      if (sh.in_flight == 16) PA_LAUNCH_APPEND(4, 16); else if (sh.in_flight == 8) PA_LAUNCH_APPEND(4, 8); else PA_LAUNCH_APPEND(4, 4);
+    }
+#undef PA_LAUNCH_APPEND
     PA_CHECK_LAUNCH(what);
     return PA_OK;
   }
@@ -565,16 +635,15 @@ static void launch_rotary_append(const int64_t* positions, void* query, void* ke
                                  int block_size, int64_t query_stride, int64_t key_stride, int64_t value_stride,
                                  hipStream_t st) {
   constexpr int X = 16 / (int)sizeof(T);
-  const int tile_vecs = num_heads * head_size * (block_size / X);
-  int sl = (2048 + num_tokens - 1) / num_tokens;  // ~8 workgroups per CU, as for pa_token_append_kernel
-  const int most = (tile_vecs + 4 * 256 - 1) / (4 * 256);
-  if (sl > most) sl = most;
-  if (sl < 1) sl = 1;
-  hipLaunchKernelGGL((pa_rotary_append_kernel<T>), dim3(num_tokens, sl), dim3(256), 0, st, positions,
-                     static_cast<T*>(query), static_cast<T*>(key), static_cast<const T*>(value),
-                     static_cast<const T*>(cos_sin_cache), static_cast<char*>(key_cache), static_cast<char*>(value_cache),
-                     slot_mapping, num_tokens, num_heads, head_size, rot_dim, block_size, query_stride, key_stride,
-                     value_stride);
+  const AppendShape sh = append_shape(num_tokens, num_heads * head_size * (block_size / X));
+#define PA_LAUNCH_ROTARY_APPEND(U)                                                                                   \
+  hipLaunchKernelGGL((pa_rotary_append_kernel<T, U>), dim3(num_tokens, sh.slices), dim3(256), 0, st, positions,     \
+                     static_cast<T*>(query), static_cast<T*>(key), static_cast<const T*>(value),                      \
+                     static_cast<const T*>(cos_sin_cache), static_cast<char*>(key_cache), static_cast<char*>(value_cache), \
+                     slot_mapping, num_tokens, num_heads, head_size, rot_dim, block_size, query_stride, key_stride,  \
+                     value_stride)
+  if (sh.in_flight == 16) PA_LAUNCH_ROTARY_APPEND(16); else if (sh.in_flight == 8) PA_LAUNCH_ROTARY_APPEND(8); else PA_LAUNCH_ROTARY_APPEND(4);
+#undef PA_LAUNCH_ROTARY_APPEND
 }
 
 // ---- copy_blocks ---------------------------------------------------------------

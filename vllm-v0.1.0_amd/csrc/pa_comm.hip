@@ -25,14 +25,20 @@
 // whole L2, which stalls every other kernel on the GPU (measured in the decode kernel: a few
 // hundred workgroups fencing once each made a 170 us launch take 1.7 ms) — and the all-reduce
 // is meant to run beside the attention kernels.  Instead every access to memory that another
-// rank writes or reads is itself a relaxed system-scope atomic (8-byte stores that write
-// through to the destination, 8-byte loads that pass the caches), a wave waits for its stores
+// rank writes or reads bypasses the caches at system scope (16-byte `sc0 sc1` stores that write
+// through to the destination, 16-byte `sc0 sc1` loads that pass the caches: one full-width
+// packet per lane on the link, not two), a wave waits for its stores
 // to be acknowledged (s_waitcnt vmcnt(0)) before its workgroup counts as arrived, and the
-// flags are relaxed system-scope atomics in uncached memory.  Every wait is bounded (kWaitTicks of the 100 MHz wall clock): a rank whose
-// peers never arrive gives up, counts a timeout that pa_comm_status reports, and finishes the
-// launch with a result of NaNs rather than hanging the GPU.  From then on the communicator
-// is broken for good: later reduces on it wait for nobody (NaN results, counted), so the cost of a
-// dead peer is one bounded wait, not one per reduce; recovery is a new communicator.
+// flags are relaxed system-scope atomics in uncached memory.  Every wait is bounded (the
+// communicator's wait budget, pa_comm_set_wait_budget, in ticks of the 100 MHz wall clock;
+// kDefaultWaitTicks unless set): a rank whose peers do not arrive within it gives up, counts a
+// timeout that pa_comm_status reports, and finishes the launch with a result of NaNs rather
+// than hanging the GPU.  From then on the communicator is broken for good: later reduces on it
+// do not wait (a peer whose flag is already there is still summed, every other reduce gives NaN
+// and is counted), so the cost of a dead peer is one bounded wait, not one per reduce; recovery
+// is a new communicator.  The budget must cover the longest host-side stall a healthy rank can
+// have between two reduces (graph capture, code-object load, a profiler attaching): the callers
+// check pa_comm_status where they synchronise anyway and stop on a timeout instead of serving NaNs.
 //
 // The sequence number lives in device memory, not in the kernel arguments, so a captured launch
 // can be replayed from a HIP graph.
@@ -55,7 +61,8 @@ namespace pa {
 constexpr int kCommMaxRanks = 8;
 constexpr int kCommThreads = 256;
 constexpr int kCommMaxWorkgroups = 128;
-constexpr unsigned long long kWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+constexpr unsigned long long kTicksPerSecond = 100000000ull;           // the wall clock (s_memrealtime) runs at 100 MHz
+constexpr unsigned long long kDefaultWaitTicks = 30 * kTicksPerSecond;  // serving default: 30 s
 constexpr size_t kTwoShotSavedBytes = 256 * 1024;         // see pa_comm_all_reduce
 
 // control words of a rank, in uncached device memory
@@ -72,6 +79,7 @@ struct CommArgs {
   void* data;                     // this rank's buffer: contribution in, sum out
   size_t slot_bytes;
   size_t n16;                     // 16-byte vectors in the message
+  unsigned long long wait_ticks;  // how long a wait for a peer may last
   int rank;
   int world;
 };
@@ -130,18 +138,42 @@ template <> struct Acc<__bf16> {
   }
 };
 
-// 16 bytes to / from memory shared with other ranks: two relaxed system-scope atomics each, i.e.
-// write-through stores and cache-bypassing loads (see the note on fences above).
-__device__ __forceinline__ void store_shared(char* p, u32x4 v) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-  __hip_atomic_store(q, (unsigned long long)v[0] | ((unsigned long long)v[1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(q + 1, (unsigned long long)v[2] | ((unsigned long long)v[3] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ u32x4 load_shared(const char* p) {
-  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<char*>(p));
-  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return u32x4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+// 16 bytes to / from memory shared with other ranks: ONE system-scope access that bypasses the
+// caches (see the note on fences above) — buffer instructions with the sc0 and sc1 bits, which
+// exist in 16-byte width (the widest atomic the compiler offers is 8 bytes, and two of those
+// would put two packets per lane on an xGMI link).  A Window is the buffer descriptor of one
+// rank's share of an inbox (base + 32-bit byte offsets; built from wave-uniform values).
+constexpr int kAuxSystemScope = 17;  // sc0 | sc1
+typedef unsigned int v4u32 __attribute__((__vector_size__(16)));
+struct Window {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ explicit Window(const char* base)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)0xffffffffu, 0x00020000)) {}
+  __device__ __forceinline__ void store(uint32_t byte_off, u32x4 v) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v), rsrc, (int)byte_off, 0, kAuxSystemScope);
+  }
+  __device__ __forceinline__ u32x4 load(uint32_t byte_off) const {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, kAuxSystemScope));
+  }
+};
+
+// The N contributions to a vector in rank order — the peers' from this rank's inbox (slot p at
+// `mine + p * slot_bytes`, byte `at` of the slot), this rank's own from `own` — summed in fp32.
+template <typename T>
+__device__ __forceinline__ u32x4 sum_in_rank_order(const CommArgs& a, const char* mine, uint32_t at, u32x4 own) {
+  u32x4 v[kCommMaxRanks];
+#pragma unroll
+  for (int p = 0; p < kCommMaxRanks; p++) {  // all the loads first: they are in flight together
+    if (p < a.world && p != a.rank) v[p] = Window(mine + (size_t)p * a.slot_bytes).load(at);
+  }
+  float acc[Acc<T>::N];
+#pragma unroll
+  for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
+#pragma unroll
+  for (int p = 0; p < kCommMaxRanks; p++) {
+    if (p < a.world) Acc<T>::add(acc, p == a.rank ? own : v[p]);
+  }
+  return Acc<T>::pack(acc);
 }
 
 // The workgroup counts itself as arrived (every wave has released its stores); the last one to
@@ -172,7 +204,7 @@ __device__ __forceinline__ void wait_for_peers(const CommArgs& a, uint32_t* ctrl
   if (tid < a.world && tid != a.rank) {
     const unsigned long long t0 = wall_clock64();
     while ((int32_t)(__hip_atomic_load(&ctrl[flag0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - k) < 0) {
-      if (broken || wall_clock64() - t0 > kWaitTicks) {
+      if (broken || wall_clock64() - t0 > a.wait_ticks) {
         __hip_atomic_fetch_add(&ctrl[kTimeouts], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *gave_up = 1;  // LDS; every writer stores the same value
         break;
@@ -216,50 +248,34 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     // 1. push this rank's contribution into slot `rank` of every peer's inbox
     for (size_t i = first; i < a.n16; i += stride) {
       const u32x4 v = data[i];
-      for (int p = 0; p < a.world; p++) {
-        if (p == a.rank) continue;
-        store_shared(a.inbox[p] + my_slot + i * 16, v);
+#pragma unroll
+      for (int p = 0; p < kCommMaxRanks; p++) {
+        if (p < a.world && p != a.rank) Window(a.inbox[p] + my_slot).store((uint32_t)(i * 16), v);
       }
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
     // 2. wait for every peer's contribution to this reduce
     wait_for_peers(a, ctrl, kFlag0, k, broken, &gave_up);
     // 3. sum the contributions in rank order, in place over this rank's own
-    for (size_t i = first; i < a.n16; i += stride) {
-      float acc[Acc<T>::N];
-#pragma unroll
-      for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
-      for (int p = 0; p < a.world; p++) {
-        const u32x4 v = p == a.rank ? data[i] : load_shared(mine + (size_t)p * a.slot_bytes + i * 16);
-        Acc<T>::add(acc, v);
-      }
-      data[i] = Acc<T>::pack(acc);
-    }
+    for (size_t i = first; i < a.n16; i += stride) data[i] = sum_in_rank_order<T>(a, mine, (uint32_t)(i * 16), data[i]);
   } else {
     // rank c owns vectors [c * q, (c + 1) * q) of the message
     const size_t q = (a.n16 + a.world - 1) / a.world;
     // 1. push every peer the part of this rank's contribution that the peer owns
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
-      if (c != a.rank) store_shared(a.inbox[c] + my_slot + (i - (size_t)c * q) * 16, data[i]);
+      if (c != a.rank) Window(a.inbox[c] + my_slot).store((uint32_t)((i - (size_t)c * q) * 16), data[i]);
     }
     arrive_and_signal(a, ctrl, kArrived, kFlag0, k, &last_to_arrive);
     wait_for_peers(a, ctrl, kFlag0, k, broken, &gave_up);
     // 2. sum the chunk this rank owns, in rank order; keep it and push it to every peer
     const size_t lo = (size_t)a.rank * q, hi = lo + q < a.n16 ? lo + q : a.n16;
     for (size_t i = lo + first; i < hi; i += stride) {
-      float acc[Acc<T>::N];
-#pragma unroll
-      for (int e = 0; e < Acc<T>::N; e++) acc[e] = 0.f;
-      for (int p = 0; p < a.world; p++) {
-        const u32x4 v = p == a.rank ? data[i] : load_shared(mine + (size_t)p * a.slot_bytes + (i - lo) * 16);
-        Acc<T>::add(acc, v);
-      }
-      const u32x4 r = Acc<T>::pack(acc);
+      const u32x4 r = sum_in_rank_order<T>(a, mine, (uint32_t)((i - lo) * 16), data[i]);
       data[i] = r;
-      for (int p = 0; p < a.world; p++) {
-        if (p == a.rank) continue;
-        store_shared(a.inbox[p] + my_slot + (q + (i - lo)) * 16, r);
+#pragma unroll
+      for (int p = 0; p < kCommMaxRanks; p++) {
+        if (p < a.world && p != a.rank) Window(a.inbox[p] + my_slot).store((uint32_t)((q + (i - lo)) * 16), r);
       }
     }
     arrive_and_signal(a, ctrl, kArrivedB, kFlagB0, k, &last_to_arrive);
@@ -267,8 +283,7 @@ __global__ void __launch_bounds__(kCommThreads) pa_comm_all_reduce_kernel(const 
     // 3. bring the other owners' sums home
     for (size_t i = first; i < a.n16; i += stride) {
       const int c = (int)(i / q);
-      if (c != a.rank)
-        data[i] = load_shared(mine + (size_t)c * a.slot_bytes + (q + (i - (size_t)c * q)) * 16);
+      if (c != a.rank) data[i] = Window(mine + (size_t)c * a.slot_bytes).load((uint32_t)((q + (i - (size_t)c * q)) * 16));
     }
   }
   // A reduce that did not hear from every peer must not pass for a sum: this workgroup's part of
@@ -288,6 +303,7 @@ struct pa_comm {
   int device = 0;
   size_t max_bytes = 0;
   size_t slot_bytes = 0;
+  unsigned long long wait_ticks = pa::kDefaultWaitTicks;
   uint32_t* ctrl = nullptr;  // own control words
   char* inbox = nullptr;     // own inbox
   bool connected = false;
@@ -426,6 +442,8 @@ extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtyp
   PA_REQUIRE(bytes % 16 == 0, "pa_comm_all_reduce: message of %zu bytes is not a multiple of 16", bytes);
   PA_REQUIRE(bytes <= c->max_bytes, "pa_comm_all_reduce: message of %zu bytes exceeds the communicator's %zu", bytes,
              c->max_bytes);
+  PA_REQUIRE(c->slot_bytes < (1ull << 31), "pa_comm_all_reduce: inbox slots of %zu bytes (offsets inside a slot are 32-bit)",
+             c->slot_bytes);
   CommArgs a;
   for (int p = 0; p < kCommMaxRanks; p++) {
     a.ctrl[p] = p < c->world ? c->peer_ctrl[p] : nullptr;
@@ -434,6 +452,7 @@ extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtyp
   a.data = data;
   a.slot_bytes = c->slot_bytes;
   a.n16 = bytes / 16;
+  a.wait_ticks = c->wait_ticks;
   a.rank = c->rank;
   a.world = c->world;
   PA_REQUIRE(algorithm == PA_COMM_AUTO || algorithm == PA_COMM_ONE_SHOT || algorithm == PA_COMM_TWO_SHOT,
@@ -461,6 +480,16 @@ extern "C" int pa_comm_all_reduce(pa_comm* c, void* data, size_t count, int dtyp
   }
 #undef PA_COMM_LAUNCH
   PA_CHECK_LAUNCH("pa_comm_all_reduce_kernel launch");
+  return PA_OK;
+}
+
+extern "C" int pa_comm_set_wait_budget(pa_comm* c, double seconds) {
+  using namespace pa;
+  clear_error();
+  PA_REQUIRE(c != nullptr, "pa_comm_set_wait_budget: null communicator");
+  PA_REQUIRE(seconds > 0.0 && seconds <= 86400.0, "pa_comm_set_wait_budget: %g seconds (0 < budget <= 86400)", seconds);
+  const double ticks = seconds * (double)kTicksPerSecond;
+  c->wait_ticks = ticks < 1.0 ? 1ull : (unsigned long long)ticks;
   return PA_OK;
 }
 

@@ -204,6 +204,15 @@ class GraphAllReduce:
         if self._in_flight[index] is not None and self._in_flight[index]._seq == seq:
             self._in_flight[index] = None
 
+    def check(self) -> None:
+        """Health of the collective behind the launcher: a reduce_fn that can fail without raising
+        (PushAllReduce: a peer that never arrived leaves NaNs) offers check(), which raises.  It
+        synchronises with the device, so the step loop calls it where it synchronises anyway (after
+        the step's tokens were sampled), before the step's results are used."""
+        fn_check = getattr(self._reduce_fn, "check", None)
+        if self._active and callable(fn_check):
+            fn_check()
+
     def launch(self, x: torch.Tensor) -> torch.Tensor:
         """x must be a leading slice of `self.buffer` (or of a ring buffer); summed over the
         group in place, ordered on the current stream like any other operation on it."""
