@@ -45,7 +45,22 @@ The JSON line also carries
                 BASELINE.json configs[1] (12 heads x 64);
   cpu_baseline  CPU statements of the path timed on this host, rank 0, N=1: the
                 C oracle on one layer of the workload, and two torch-CPU
-                statements (per-token loop, vectorised gather) on a slice.
+                statements (per-token loop, vectorised gather) on a slice;
+  and, at N = 1 on the default workload, four secondary measurements of the
+  operators either side of the decode kernel, each guarded so that a failure
+  becomes an "error" entry instead of costing the line:
+  cache_write   reshape_and_cache at the step's size: us per launch (HIP-graph
+                replay over the layers), its algorithmic bytes, and the PMC
+                traffic of the committed rocprofv3 pass next to them;
+  small_batch   batches of 1 / 4 / 16 sequences through the operator with the
+                reference's signature (graph replay): us per launch, fraction
+                of the HBM peak;
+  prompt        prompt attention (the operator behind the xformers call of
+                the reference) on four LLaMA-7B prompt batches, bf16: us,
+                TFLOP/s, fraction of the 2.5 PFLOP/s dense MFMA peak;
+  decoder_step  a whole LLaMA-7B decode step on the same caches — torch GEMMs,
+                embedding, argmax, and this package's operators for the rest:
+                ms per step and tokens/s, eager and from a HIP graph.
 """
 from __future__ import annotations
 
@@ -61,6 +76,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS_16BIT = 2500.0  # dense fp16 / bf16 matrix peak (without the 2:1 sparsity of the headline figure)
 
 WORKLOADS = {
     # name: (num_heads, head_size, num_layers, description)
@@ -126,6 +142,8 @@ def parse_args(argv=None):
                    help="CPU work the C-oracle sample is sized to (one layer of the workload, repeated)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-c2", action="store_true", help="skip the secondary microbench-shape measurement")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip cache_write / small_batch / prompt / decoder_step (N = 1, default workload only)")
     p.add_argument("--no-tp-leg", action="store_true", help="N > 1 without --tp: skip the extra head-sharded measurement")
     p.add_argument("--tp-leg-deadline", type=float, default=180.0,
                    help="N > 1 without --tp: seconds the extra head-sharded legs may take before the line is printed without them")
@@ -399,6 +417,115 @@ def decode_roofline(torch, attention_ops, cache_ops, w, workspace, n_launch):
                                     "reference caller invokes; plans per call, scratch from torch's allocator; caches: "
                                     + ref_alloc,
     }
+
+
+def graph_time_us(torch, fn, per_graph, replays=7):
+    """Median microseconds per call of fn(i), i = 0 .. per_graph - 1, replayed from one HIP graph
+    (the host's launch cost is not in the figure)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(min(per_graph, 3)):
+            fn(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(per_graph):
+            fn(i)
+    graph.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(replays):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / per_graph * 1e3)
+    return median(sorted(ts))
+
+
+def guarded(extra, key, fn):
+    """extra[key] = fn(), or what went wrong: a secondary measurement never costs the line."""
+    try:
+        extra[key] = fn()
+    except Exception as e:  # noqa: BLE001
+        extra[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+
+
+def cache_write_measurement(torch, cache_ops, args, w):
+    """reshape_and_cache of the step's new tokens, one launch per layer, replayed from a graph."""
+    us = graph_time_us(torch, lambda i: cache_ops.reshape_and_cache(
+        w.key, w.value, w.key_caches[i % w.L], w.value_caches[i % w.L], w.slot_mapping), w.L)
+    moved = 2 * 2 * w.S * w.H * w.D * w.es + 4 * w.S  # K and V rows read, the same bytes written, the slots read
+    traffic, source = pmc_traffic("pa_token_append_kernel", args)
+    # the kernel rewrites the whole value tile of every block it appends to (full lines instead of one
+    # 2-byte element in each of the tile's rows): what it has to move is the K rows in and out, the V
+    # rows in, and every touched value tile in and out
+    tile_bytes = w.H * w.D * w.B * w.es
+    moves = 2 * w.S * w.H * w.D * w.es + w.S * w.H * w.D * w.es + 2 * w.S * tile_bytes + 4 * w.S
+    res = {"kernel": "pa_token_append_kernel (cache_ops.reshape_and_cache, decode-sized batch)",
+           "us_per_launch": us, "tokens": w.S, "algorithmic_bytes": moved,
+           "bytes_the_kernel_moves": moves, "achieved_gbps_on_moved_bytes": moves / us / 1e3,
+           "frac_of_hbm_peak_on_moved_bytes": moves / us / 1e3 / HBM_PEAK_GBPS,
+           "timing": f"HIP-graph replay of {w.L} launches, one per layer's caches; median of 7 replays",
+           "traffic": traffic, "traffic_source": source}
+    if traffic:
+        res["traffic_over_algorithmic"] = traffic / moved
+    return res
+
+
+def small_batch_measurement(torch, attention_ops, w):
+    """Few sequences through attention_ops.single_query_cached_kv_attention (the reference's signature:
+    sizes its scratch and plans its launch per call), on slices of the workload's caches, a different
+    layer's memory for every launch of a replay."""
+    res = {"entry": "attention_ops.single_query_cached_kv_attention (reference signature), HIP-graph replay of one "
+                    f"launch per layer's caches, {w.H} heads x {w.D}, ctx {w.CTX}, block {w.B}",
+           "shapes": []}
+    for S in (1, 4, 16):
+        if S > w.S:
+            continue
+        q, out = w.query[:S], w.out[:S]
+        bt, cl = w.block_tables[:S].contiguous(), w.context_lens[:S].contiguous()
+        us = graph_time_us(torch, lambda i: attention_ops.single_query_cached_kv_attention(
+            out, q, w.key_caches[i % w.L], w.value_caches[i % w.L], w.scale, bt, cl, w.B, w.CTX), w.L)
+        nbytes = algorithmic_bytes(w.ctx_list[:S], w.H, w.D, w.B, w.es)
+        res["shapes"].append({"batch": S, "us_per_launch": us, "bytes_per_launch": nbytes,
+                              "achieved_gbps": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBPS})
+    return res
+
+
+def prompt_measurement(torch, attention_ops, device, H, D):
+    """Prompt attention on LLaMA-7B-shaped prompt batches (bf16): causal FLOPs = 4 H D sum n (n + 1) / 2."""
+    res = {"kernel": "pa_prompt_kernel (attention_ops.multi_query_kv_attention)", "dtype": "bf16", "bound": "mfma",
+           "peak": MFMA_PEAK_TFLOPS_16BIT, "unit": "TFLOP/s", "heads": H, "head_size": D,
+           "timing": "HIP-graph replay of 5 launches; median of 7 replays", "shapes": []}
+    for lens in ([512] * 5, [2560], [2048] * 8, [16384]):
+        T = sum(lens)
+        qkv = torch.randn(T, 3, H, D, dtype=torch.bfloat16, device=device)
+        q, k, v = qkv.unbind(dim=1)
+        out = torch.empty(T, H, D, dtype=torch.bfloat16, device=device)
+        us = graph_time_us(torch, lambda i: attention_ops.multi_query_kv_attention(out, q, k, v, lens, D ** -0.5), 5)
+        flops = 4 * H * D * sum(n * (n + 1) // 2 for n in lens)
+        res["shapes"].append({"prompts": f"{len(lens)} x {lens[0]}", "tokens": T, "us_per_launch": us, "flops": flops,
+                              "achieved": flops / us / 1e6, "frac": flops / us / 1e6 / MFMA_PEAK_TFLOPS_16BIT})
+        del qkv, out
+    return res
+
+
+def decoder_step_measurement(pkg, w):
+    """A whole LLaMA-7B decode step around the path, on the workload's caches and block tables."""
+    tools = os.path.join(ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import bench_decoder_step
+    r = bench_decoder_step.decoder_step(pkg, "7b", batch=w.S, ctx=w.CTX, steps=5,
+                                        caches=list(zip(w.key_caches, w.value_caches)), block_tables=w.block_tables)
+    r["what"] = ("embedding, 32 x (rms_norm, qkv GEMM, rotary + reshape_and_cache, single_query_cached_kv_attention, o_proj "
+                 "GEMM, rms_norm, gate_up GEMM, silu_and_mul, down GEMM), final norm, logits GEMM, argmax; random weights; "
+                 "torch GEMMs, this package's operators for the rest")
+    return r
 
 
 def tp_leg(torch, dist, device, pkg, args, H, D, L, tdtype, model_name, shared_caches=None, emulate=0, collective=None):
@@ -863,6 +990,15 @@ def main(argv=None):
         if not line_lock.acquire(blocking=False):
             time.sleep(3600)  # the deadline passed at this very moment: its thread prints and ends the process
         deadline.cancel()
+
+    # ---- the operators either side of the decode kernel (N = 1, default workload) --------------------
+    default_workload = (args.workload, args.dtype, args.block_size) == ("llama7b", "float16", 16)
+    if not args.no_secondary and not args.no_roofline and dist.world == 1 and default_workload:
+        progress(dist, "secondary measurements")
+        guarded(extra, "cache_write", lambda: cache_write_measurement(torch, cache_ops, args, w))
+        guarded(extra, "small_batch", lambda: small_batch_measurement(torch, attention_ops, w))
+        guarded(extra, "prompt", lambda: prompt_measurement(torch, attention_ops, device, H, D))
+        guarded(extra, "decoder_step", lambda: decoder_step_measurement(pkg, w))
 
     # ---- CPU baseline --------------------------------------------------------------------------------
     if not args.no_cpu_baseline and dist.rank == 0 and dist.world == 1:

@@ -132,8 +132,12 @@ int pa_single_query_cached_kv_attention_ws(
  * carries a stamp of the sizes it was made for: with a workspace whose plan
  * was never made, or made for other sizes, the call fills `out` with NaN
  * instead of computing anything, so that the caller's error cannot pass for a
- * result.  A plan made from other context_lens of the same sizes gives wrong
- * results.  pa_single_query_cached_kv_attention_ws makes the
+ * result.  A plan reused after context_lens changed (same sizes, other
+ * contents) is caught per sequence: the plan records the length of every
+ * sequence it placed or partitioned, and the output rows of a sequence whose
+ * length differs from the recorded one are filled with NaN (the other rows
+ * are correct: the plan only decides where and in how many pieces a row is
+ * computed).  pa_single_query_cached_kv_attention_ws makes the
  * plan on every call, and makes the row order only for launches big enough to
  * win it back.  total_context_len is the sum of context_lens if the caller
  * knows it on the host (the engine builds context_lens from a host list), else

@@ -16,11 +16,16 @@ def _run_capi(pkg, inp, case, device="cuda:0", split=False):
     row).  split=True: the _planned entry point (plan made by this call) with
     the workspace it asks for, so small batches take the partitioned kernel +
     merge kernel, big ones with long contexts the item list, and batches of 16
-    units of sequences and more the balanced row order."""
+    units of sequences and more the balanced row order.  split="module": the
+    attention_ops function with the reference's own signature
+    (csrc/attention.cpp:3-19), what the unchanged reference caller invokes."""
     import torch
     qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, device)
     out = torch.full((case.num_seqs, case.num_heads, case.head_size), float("nan"), dtype=qkv.dtype, device=device)
-    if split:
+    if split == "module":
+        pkg.attention_ops.single_query_cached_kv_attention(
+            out, query, kc, vc, inp["scale"], bt, cl, case.block_size, inp["max_context_len"])
+    elif split:
         nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size,
                                                   case.block_size, inp["max_context_len"])
         ws = torch.full((max(nbytes, 4) // 4,), float("nan"), dtype=torch.float32, device=device)
@@ -34,12 +39,13 @@ def _run_capi(pkg, inp, case, device="cuda:0", split=False):
     return out
 
 
-@pytest.mark.parametrize("split", [False, True], ids=["rows", "partitioned"])
+@pytest.mark.parametrize("split", [False, True, "module"], ids=["rows", "partitioned", "module"])
 @pytest.mark.parametrize("name", sorted(DECODE_META))
 def test_decode_matches_reference_fixture(pkg, name, split):
     """Every golden case: dtype x block size x head size grid at two input
     scales, edge-case context lengths, and the reference test's own sizes
-    (37 tokens, 3 heads, 1024 blocks, context <= 4096)."""
+    (37 tokens, 3 heads, 1024 blocks, context <= 4096) — through the C ABI's two
+    forms and through the module function with the reference's signature."""
     entry = DECODE_META[name]
     case = helpers.decode_case_from_meta(entry)
     inp = datagen.make_decode_inputs(case)
@@ -626,6 +632,127 @@ def test_decode_with_a_workspace_that_holds_no_plan_poisons_the_output(pkg, long
                                                                ws[:nbytes // 4], ready)
             torch.cuda.synchronize()
             helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"S={S} ready={ready}")
+
+
+def _balanced_slots_per_xcd(S, H):
+    """Slots per XCD of the balanced order's row table (the library's plan_balance rule)."""
+    group = min(max(128 // H, 1), 16)
+    unit = min(4, group)
+    group = group // unit * unit
+    units = (S + unit - 1) // unit
+    assert units >= 16
+    return ((units + 7) // 8 * unit + group - 1) // group * group
+
+
+def test_decode_item_list_with_a_foreign_row_table_poisons_every_row(pkg):
+    """Item-list form on top of the balanced order: the list's stamp (counters) is intact but the row
+    table's is not (its words were overwritten).  Every output row must come out NaN — also the rows whose
+    index is below the number of workgroup ids reserved for listed partitions."""
+    import torch
+    rng = np.random.default_rng(18)
+    S, H, D, B, longest = 100, 8, 64, 16, 2600
+    ctx = [int(c) for c in rng.integers(1, longest + 1, size=S)]
+    ctx[3] = longest
+    case = datagen.DecodeCase(name="stamp", dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                              num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                              tables="permutation", seed=640)
+    inp = datagen.make_decode_inputs(case)
+    qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
+    ws = torch.zeros(nbytes // 4 + 1, dtype=torch.int32, device="cuda:0")
+    out = torch.full((S, H, D), 7.0, dtype=qkv.dtype, device="cuda:0")
+    args = (out, query, kc, vc, inp["scale"], bt, cl, B, longest, ws[:nbytes // 4])
+    pkg._capi.single_query_cached_kv_attention_planned(*args, False)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(out.float()).any())
+    at = 8 * _balanced_slots_per_xcd(S, H) * 2  # the stamp sits behind the table's [8][slots] (sequence, length) pairs
+    stamp = ws[at:at + 2].tolist()
+    assert stamp[0] & 1 and (stamp[0] ^ stamp[1]) & 0xffffffff == 0xffffffff, stamp
+    ws[at] ^= 0x10
+    out.fill_(7.0)
+    pkg._capi.single_query_cached_kv_attention_planned(*args, True)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out.float()).all()), "rows kept stale values although the row table's stamp does not match"
+
+
+@pytest.mark.parametrize("longest", [300, 2600], ids=["rows", "item_list"])
+def test_decode_plan_reused_after_context_lens_changed_poisons_the_changed_rows(pkg, longest):
+    """A plan depends on context_lens.  A caller that reuses one (plan_ready=True) after some lengths
+    changed — same sizes, other contents — must not get plausible numbers for those sequences: their rows
+    come out NaN; the rows of the unchanged sequences are still right (the plan only decides where and in
+    how many pieces a row is computed)."""
+    import torch
+    rng = np.random.default_rng(28)
+    S, H, D, B = 100, 8, 64, 16
+    ctx = [int(c) for c in rng.integers(1, longest + 1, size=S)]
+    ctx[3] = longest
+    changed = {5: 17, 40: longest - 3, 41: ctx[41] + 1 if ctx[41] < longest else ctx[41] - 1, 99: 1}
+    changed = {k: v for k, v in changed.items() if v != ctx[k]}
+    assert len(changed) >= 3
+    ctx2 = [changed.get(i, c) for i, c in enumerate(ctx)]
+    case = datagen.DecodeCase(name="stale", dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                              num_blocks=S * ((longest + B - 1) // B) + 5, context_lens=ctx2, dist="normal",
+                              tables="permutation", seed=650)
+    inp = datagen.make_decode_inputs(case)
+    qkv, query, kc, vc, bt, cl2 = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+    cl = torch.tensor(ctx, dtype=torch.int32, device="cuda:0")
+    nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, longest)
+    ws = torch.zeros(nbytes // 4 + 1, dtype=torch.int32, device="cuda:0")
+    out = torch.full((S, H, D), 7.0, dtype=qkv.dtype, device="cuda:0")
+    # the plan is made from ctx (the tables are wide enough for either set of lengths) ...
+    pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, longest,
+                                                       ws[:nbytes // 4], False)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(out.float()).any())
+    # ... and reused with ctx2
+    out.fill_(7.0)
+    pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl2, B, longest,
+                                                       ws[:nbytes // 4], True)
+    torch.cuda.synchronize()
+    got = helpers.out_to_f32(out, case.dtype)
+    ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], case.dtype), case.dtype)
+    same = [i for i in range(S) if i not in changed]
+    for i in changed:
+        assert np.isnan(got[i]).all(), f"sequence {i}: length changed under a reused plan, row not poisoned"
+    atol, rtol = helpers.TIGHT[case.dtype]
+    helpers.assert_close(got[same], ref[same], atol, 2 * rtol, "unchanged sequences under a reused plan")
+
+
+def _storage_inputs_as_float32(inp, dtype):
+    """The same numbers as float32 arrays in float32's cache layout (x = 4 instead of 8)."""
+    f = lambda a: datagen.storage_to_float32(a, dtype)  # noqa: E731
+    kc = f(inp["key_cache"])
+    NB, H, DX, B, X = kc.shape
+    D = DX * X
+    kc = kc.transpose(0, 1, 3, 2, 4).reshape(NB, H, B, D).reshape(NB, H, B, D // 4, 4).transpose(0, 1, 3, 2, 4)
+    return f(inp["qkv"])[:, 0], np.ascontiguousarray(kc), f(inp["value_cache"])
+
+
+@pytest.mark.parametrize("entry", ["rows", "partitioned"])
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_decode_is_no_further_from_exact_than_the_reference_kernels_own_arithmetic(pkg, dtype, entry):
+    """The oracle's mode 1 follows the reference CUDA kernel's rounding points (weights rounded to the
+    storage type, products and 8-wide partial sums in it, csrc/attention/attention_kernels.cu:236-254);
+    mode 0 on float32 copies of the inputs is the exact result.  This kernel rounds less (fp16: nothing
+    before the output; bfloat16: the weights once per block, products exact), so on unit-scale inputs its
+    error against the exact result must not exceed the reference arithmetic's own — in the root mean
+    square and at the worst element.  A second net under the per-element bfloat16 bound of decode_atol."""
+    case = datagen.DecodeCase(name="closer", dtype=dtype, num_seqs=24, num_heads=4, head_size=128, block_size=16,
+                              num_blocks=24 * 45 + 3, max_context=700, dist="normal", tables="permutation", seed=77)
+    inp = datagen.make_decode_inputs(case)
+    q32, kc32, vc32 = _storage_inputs_as_float32(inp, dtype)
+    exact = pa_oracle.single_query_cached_kv_attention(q32, kc32, vc32, inp["scale"], inp["block_tables"],
+                                                       inp["context_lens"], "float32").astype(np.float64)
+    ref_kernel = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+        inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+        inp["context_lens"], dtype, mode=1), dtype).astype(np.float64)
+    got = helpers.out_to_f32(_run_capi(pkg, inp, case, split=entry == "partitioned"), dtype).astype(np.float64)
+    err_ref, err_got = np.abs(ref_kernel - exact), np.abs(got - exact)
+    rms = lambda e: float(np.sqrt(np.mean(e * e)))  # noqa: E731
+    assert rms(err_got) <= 1.02 * rms(err_ref), (rms(err_got), rms(err_ref))
+    assert err_got.max() <= 1.25 * err_ref.max(), (err_got.max(), err_ref.max())
 
 
 # ---- per-GPU shapes of the tensor-parallel configurations ---------------------

@@ -31,16 +31,38 @@ def _both(pkg, case):
     nbytes = pkg._capi.decode_workspace_bytes(case.num_seqs, case.num_heads, case.head_size, B, mc)
     ws = torch.full((max(nbytes, 4) // 4,), float("nan"), dtype=torch.float32, device=dev) if nbytes else None
     torch.cuda.synchronize()
-    # torch's allocator counts every block and every segment it ever handed out: the counts cannot
-    # move unless something allocated (bytes in use can also DROP during the call, when Python
-    # happens to collect an earlier test's garbage)
+    # The entry point is reached through ctypes, so torch's allocator statistics would not see a
+    # hipMalloc inside the library: the check is at the driver.  (1) hipMemGetInfo's free bytes do
+    # not move across the call — after one warm-up call on this device, which loads the code object
+    # and resolves the scratch symbol's address; torch's counters are watched too, so that a change
+    # of the free bytes cannot be an allocation of torch's own.  (2) The call is captured into a HIP
+    # graph in the capture mode in which hipMalloc, hipFree and every synchronising call are errors,
+    # and the replay gives the same bits.
     def handed_out():
         st = torch.cuda.memory_stats()
         return st["allocation.all.allocated"], st["segment.all.allocated"]
-    before = handed_out()
-    pkg._capi.single_query_cached_kv_attention_static(out_static, query, kc, vc, inp["scale"], bt, cl, B, mc)
+
+    def call(out):
+        pkg._capi.single_query_cached_kv_attention_static(out, query, kc, vc, inp["scale"], bt, cl, B, mc)
+    call(out_static)  # warm-up
+    torch.cuda.synchronize()
+    out_static.fill_(float("nan"))
+    torch.cuda.synchronize()
+    before, free_before = handed_out(), torch.cuda.mem_get_info()[0]
+    call(out_static)
     torch.cuda.synchronize()
     assert handed_out() == before
+    assert torch.cuda.mem_get_info()[0] == free_before, "device memory was allocated or freed inside the call"
+    out_graph = torch.full(shape, float("nan"), dtype=qkv.dtype, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side, capture_error_mode="global"):
+        pkg._capi.single_query_cached_kv_attention_static(out_graph, query, kc, vc, inp["scale"], bt, cl, B, mc,
+                                                          stream=side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph, out_static), "the captured call replays to other bits than the eager call"
     pkg._capi.single_query_cached_kv_attention_ws(out_ws, query, kc, vc, inp["scale"], bt, cl, B, mc, ws)
     torch.cuda.synchronize()
     ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(

@@ -25,29 +25,23 @@ MODELS = {"7b": dict(hidden=4096, inter=11008, heads=32, layers=32, vocab=32000)
           "13b": dict(hidden=5120, inter=13824, heads=40, layers=40, vocab=32000)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="7b")
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--ctx", type=int, default=1024)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--layers", type=int, default=0)
-    ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--two-call-rotary", action="store_true",
-                    help="rotary_embedding_neox then reshape_and_cache as two calls (the reference's sequence) instead "
-                         "of the one-pass operator for the generation tokens")
-    args = ap.parse_args()
-    pkg = __graft_entry__.load_package()
+def decoder_step(pkg, model="7b", batch=256, ctx=1024, steps=10, num_layers=0, two_call_rotary=False, profile=False,
+                 caches=None, block_tables=None, graph=True):
+    """Builds the step and times it.  caches: [(key_cache, value_cache)] per layer to run on (fp16, block 16,
+    at least batch * ceil(ctx / 16) blocks each) with their block_tables [batch, ceil(ctx / 16)]; default: allocated
+    here.  Returns a dict: eager_ms, graph_ms, tokens_per_s, the bytes a step must stream, and (profile=True) the
+    device time per operator class."""
     from vllm_amd.input_metadata import InputMetadata
     from vllm_amd.layers import PagedAttentionWithRoPE, RMSNorm, SiluAndMul
 
-    m = MODELS[args.model]
+    m = MODELS[model]
     hidden, inter, H, vocab = m["hidden"], m["inter"], m["heads"], m["vocab"]
-    L = args.layers or m["layers"]
-    D, B, S, CTX = hidden // H, 16, args.batch, args.ctx
-    dev, dt = torch.device("cuda:0"), torch.float16
+    L = num_layers or m["layers"]
+    if caches is not None:
+        L = min(L, len(caches))
+    D, B, S, CTX = hidden // H, 16, batch, ctx
+    dev, dt = torch.device("cuda", torch.cuda.current_device()), torch.float16
     torch.manual_seed(0)
-    torch.set_default_dtype(dt)
 
     def w(*shape):
         return torch.empty(*shape, dtype=dt, device=dev).normal_(0, 0.02)
@@ -56,21 +50,25 @@ def main():
     layers = []
     bps = (CTX + B - 1) // B
     NB = S * bps
-    for _ in range(L):
+    for l in range(L):
+        if caches is not None:
+            kc, vc = caches[l]
+        else:
+            kc = torch.empty(NB, H, D // 8, B, 8, dtype=dt, device=dev).normal_(0, 0.5)
+            vc = torch.empty(NB, H, D, B, dtype=dt, device=dev).normal_(0, 0.5)
         layers.append(dict(
-            ln1=RMSNorm(hidden).to(dev), ln2=RMSNorm(hidden).to(dev), qkv=w(hidden, 3 * hidden), o=w(hidden, hidden),
-            gate_up=w(hidden, 2 * inter), down=w(inter, hidden),
-            kc=torch.empty(NB, H, D // 8, B, 8, dtype=dt, device=dev).normal_(0, 0.5),
-            vc=torch.empty(NB, H, D, B, dtype=dt, device=dev).normal_(0, 0.5)))
-    final_norm = RMSNorm(hidden).to(dev)
+            ln1=RMSNorm(hidden).to(device=dev, dtype=dt), ln2=RMSNorm(hidden).to(device=dev, dtype=dt),
+            qkv=w(hidden, 3 * hidden), o=w(hidden, hidden), gate_up=w(hidden, 2 * inter), down=w(inter, hidden), kc=kc, vc=vc))
+    final_norm = RMSNorm(hidden).to(device=dev, dtype=dt)
     cache_ops = None
-    if args.two_call_rotary:
+    if two_call_rotary:
         import types
         cache_ops = types.SimpleNamespace(reshape_and_cache=pkg.cache_ops.reshape_and_cache)
-    attn = PagedAttentionWithRoPE(H, D, D ** -0.5, rotary_dim=D, max_position=2048, cache_ops=cache_ops).to(dev)
+    attn = PagedAttentionWithRoPE(H, D, D ** -0.5, rotary_dim=D, max_position=2048, cache_ops=cache_ops).to(device=dev, dtype=dt)
     act = SiluAndMul()
-    g = torch.Generator(device="cpu").manual_seed(0)
-    block_tables = torch.randperm(NB, generator=g).to(torch.int32).reshape(S, bps).to(dev)
+    if block_tables is None:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        block_tables = torch.randperm(NB, generator=g).to(torch.int32).reshape(S, bps).to(dev)
     context_lens = torch.full((S,), CTX, dtype=torch.int32, device=dev)
     pos = CTX - 1
     slot_mapping = (block_tables[:, pos // B].long() * B + pos % B).to(torch.int32)
@@ -104,54 +102,81 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / n
 
-    eager_ms = time_it(step, args.steps)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        step()
-    torch.cuda.current_stream().wait_stream(s)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        step()
-    graph.replay()
-    torch.cuda.synchronize()
-    graph_ms = time_it(graph.replay, args.steps)
+    res = {"model": f"LLaMA-{model}", "batch": S, "context_len": CTX, "layers": L, "dtype": "f16",
+           "rotary_cache_write": "two calls" if two_call_rotary else "one pass"}
+    res["eager_ms"] = time_it(step, steps)
+    if graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step()
+        cg.replay()
+        torch.cuda.synchronize()
+        res["graph_ms"] = time_it(cg.replay, steps)
+    best = min(res["eager_ms"], res.get("graph_ms", res["eager_ms"]))
+    res["tokens_per_s"] = S / best * 1e3
     wbytes = sum(t.numel() * 2 for ly in layers for t in (ly["qkv"], ly["o"], ly["gate_up"], ly["down"])) + lm_head.numel() * 2
     kvbytes = L * 2 * S * CTX * H * D * 2
-    print(f"LLaMA-{args.model} decode step, batch {S}, ctx {CTX}, {L} layers, fp16, random weights, "
-          f"{'rotary + reshape_and_cache as two calls' if args.two_call_rotary else 'rotary + reshape_and_cache in one pass'}")
-    print(f"  eager : {eager_ms:8.2f} ms/step  {S / eager_ms * 1e3:10.0f} tokens/s")
-    print(f"  graph : {graph_ms:8.2f} ms/step  {S / graph_ms * 1e3:10.0f} tokens/s")
-    print(f"  bytes that must stream per step: weights {wbytes / 1e9:.1f} GB + KV {kvbytes / 1e9:.1f} GB "
-          f"= {(wbytes + kvbytes) / 8e12 * 1e3:.2f} ms at 8 TB/s")
-    if args.no_profile:
-        return
-    from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-    groups = {}
-    for ev in prof.key_averages():
-        name = ev.key
-        t = getattr(ev, "device_time_total", None) or getattr(ev, "cuda_time_total", 0)
-        if "pa_decode" in name:
-            key = "paged attention (decode)"
-        elif "pa_rotary_append" in name:
-            key = "rotary + reshape_and_cache (one pass)"
-        elif "pa_token" in name:
-            key = "reshape_and_cache"
-        elif "rms_norm" in name or "rotary" in name or "silu" in name:
-            key = "rms_norm / rotary / silu_and_mul"
-        elif "Cijk" in name or "gemm" in name.lower() or "hipblas" in name.lower():
-            key = "GEMMs (hipBLASLt / rocBLAS)"
-        else:
-            key = "other (adds, embedding, argmax, copies)"
-        groups[key] = groups.get(key, 0.0) + t / 3
-    total = sum(groups.values())
-    print("  device time per step by operator class (torch profiler, eager):")
-    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]):
-        print(f"    {k:42s} {v / 1e3:8.2f} ms  {100 * v / total:5.1f} %")
+    res["weight_bytes"], res["kv_bytes"] = wbytes, kvbytes
+    res["ms_at_8_TBps"] = (wbytes + kvbytes) / 8e12 * 1e3
+    if profile:
+        from torch.profiler import ProfilerActivity, profile as torch_profile
+        with torch_profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        groups = {}
+        for ev in prof.key_averages():
+            name = ev.key
+            t = getattr(ev, "device_time_total", None) or getattr(ev, "cuda_time_total", 0)
+            if "pa_decode" in name:
+                key = "paged attention (decode)"
+            elif "pa_rotary_append" in name:
+                key = "rotary + reshape_and_cache (one pass)"
+            elif "pa_token" in name:
+                key = "reshape_and_cache"
+            elif "rms_norm" in name or "rotary" in name or "silu" in name:
+                key = "rms_norm / rotary / silu_and_mul"
+            elif "Cijk" in name or "gemm" in name.lower() or "hipblas" in name.lower():
+                key = "GEMMs (hipBLASLt / rocBLAS)"
+            else:
+                key = "other (adds, embedding, argmax, copies)"
+            groups[key] = groups.get(key, 0.0) + t / 3
+        res["device_ms_by_class"] = {k: v / 1e3 for k, v in groups.items()}
+    return res
 
 
-main()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="7b")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--ctx", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--layers", type=int, default=0)
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--two-call-rotary", action="store_true",
+                    help="rotary_embedding_neox then reshape_and_cache as two calls (the reference's sequence) instead "
+                         "of the one-pass operator for the generation tokens")
+    args = ap.parse_args()
+    pkg = __graft_entry__.load_package()
+    r = decoder_step(pkg, args.model, args.batch, args.ctx, args.steps, args.layers, args.two_call_rotary,
+                     profile=not args.no_profile)
+    print(f"{r['model']} decode step, batch {r['batch']}, ctx {r['context_len']}, {r['layers']} layers, fp16, random weights, "
+          f"rotary + reshape_and_cache: {r['rotary_cache_write']}")
+    print(f"  eager : {r['eager_ms']:8.2f} ms/step  {r['batch'] / r['eager_ms'] * 1e3:10.0f} tokens/s")
+    print(f"  graph : {r['graph_ms']:8.2f} ms/step  {r['batch'] / r['graph_ms'] * 1e3:10.0f} tokens/s")
+    print(f"  bytes that must stream per step: weights {r['weight_bytes'] / 1e9:.1f} GB + KV {r['kv_bytes'] / 1e9:.1f} GB "
+          f"= {r['ms_at_8_TBps']:.2f} ms at 8 TB/s")
+    if "device_ms_by_class" in r:
+        total = sum(r["device_ms_by_class"].values())
+        print("  device time per step by operator class (torch profiler, eager):")
+        for k, v in sorted(r["device_ms_by_class"].items(), key=lambda kv: -kv[1]):
+            print(f"    {k:42s} {v:8.2f} ms  {100 * v / total:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()

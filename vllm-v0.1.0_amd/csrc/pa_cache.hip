@@ -531,17 +531,19 @@ struct AppendShape {
   int slices;
   int in_flight;
 };
-#ifndef PA_CACHE_APPEND_IN_FLIGHT
-#define PA_CACHE_APPEND_IN_FLIGHT 4
-#endif
+// Measured on MI355X (32 heads x 128, block 16, fp16; reshape_and_cache per launch, graph replay over
+// rotating layers; vectors in flight x workgroups): 256 tokens 4 x 2048: 24.4 us, 4 x 1024 (two passes):
+// 25.1, 8 x 1024: 22.8, 16 x 512: 23.7; 64 tokens 4: 6.2, 8: 6.4, 16: 7.7; 16 tokens 4: 4.9, 8: 5.6, 16: 7.2.
+// Big batches want more bytes in flight per lane, small ones more workgroups.
+constexpr int kAppendWideTokens = 128;  // batches from this size on keep 8 vectors in flight per lane
 #ifndef PA_CACHE_APPEND_WORKGROUPS
 #define PA_CACHE_APPEND_WORKGROUPS 2048
 #endif
 static AppendShape append_shape(int num_tokens, int tile_vecs) {
-  static const int in_flight = tuning_int("PA_CACHE_APPEND_IN_FLIGHT", PA_CACHE_APPEND_IN_FLIGHT);  // 4, 8 or 16
+  static const int forced = tuning_int("PA_CACHE_APPEND_IN_FLIGHT", 0);  // tuning builds: 4, 8 or 16
   static const int target = tuning_int("PA_CACHE_APPEND_WORKGROUPS", PA_CACHE_APPEND_WORKGROUPS);
   AppendShape sh;
-  sh.in_flight = in_flight == 16 ? 16 : in_flight == 8 ? 8 : 4;
+  sh.in_flight = forced == 16 ? 16 : forced == 8 ? 8 : forced == 4 ? 4 : (num_tokens >= kAppendWideTokens ? 8 : 4);
   // about `target` workgroups in all; a slice is at least one pass of in_flight vectors per lane
   int sl = (target + num_tokens - 1) / num_tokens;
   const int most = (tile_vecs + sh.in_flight * 256 - 1) / (sh.in_flight * 256);

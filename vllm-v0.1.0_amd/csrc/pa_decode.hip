@@ -234,6 +234,7 @@ struct DecodeArgs {
   const uint32_t* items;  // kModeList: the (sequence, partition >= 1) pairs that exist, in sequence order
   unsigned* counters;     // kModeList: [0] the plan's stamp, [1] number of pairs, [2] blocks per partition in force
   unsigned list_slots;    // kModeList: workgroup ids reserved for pairs = num_seqs * (num_parts - 1) * num_heads
+  const int* planned_lens;  // kModeList: the context lengths the plan was made from, [num_seqs]
   // Append form (null = off): the step's new token of every sequence, [num_seqs][num_heads][D]
   // with these row strides in elements.  Its place is the last position of the context:
   // block_tables[seq][(ctx - 1) / B], offset (ctx - 1) % B.
@@ -245,14 +246,15 @@ struct DecodeArgs {
 };
 
 // A launch that finds no plan for its sizes in the workspace (never made, or made for another
-// batch) must not pass for a result: every output row is filled with NaN instead.  The grid of
-// every launch form has at least one workgroup per row.
+// batch) must not pass for a result: every output row is filled with NaN instead.  `row` runs
+// over a range that covers [0, rows) in every launch form: the whole grid where the item list's
+// stamp is tested, the row pass (ids behind the list's slots) where the row table's is.
 template <typename E, int D, typename Args>
-__device__ __forceinline__ void poison_output_row(const Args& a) {
+__device__ __forceinline__ void poison_output_row(const Args& a, unsigned row) {
   typedef typename E::storage T;
   const unsigned rows = (unsigned)a.num_seqs * (unsigned)a.num_heads;
-  if (blockIdx.x >= rows) return;
-  T* op = static_cast<T*>(a.out) + (int64_t)blockIdx.x * D;
+  if (row >= rows) return;
+  T* op = static_cast<T*>(a.out) + (int64_t)row * D;
   for (int d = threadIdx.x; d < D; d += blockDim.x) op[d] = E::from_float(__builtin_nanf(""));
 }
 
@@ -331,7 +333,7 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     const unsigned n_items = a.counters[1] * (unsigned)a.num_heads;
     // n_items > list_slots: more pairs than the caller's total_context_len allows for — it was not the sum
     if ((plan_stamp != a.plan_tag) | (n_items > a.list_slots)) {
-      poison_output_row<E, D>(a);
+      poison_output_row<E, D>(a, blockIdx.x);
       return;
     }
     if (blockIdx.x < a.list_slots) {
@@ -355,6 +357,11 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
   // kModeList: the partition length in force is the plan kernel's decision
   const int bpp = MODE == kModeList ? (int)a.counters[2] : a.blocks_per_part;
   int head, seq, ctx;
+  // Balanced order: the sequence's length as it is NOW, next to the one the plan was made from.
+  // A plan reused after context_lens changed (same sizes, other contents) is the caller's error;
+  // the row it would get wrong is filled with NaN instead.
+  int ctx_now = 0;
+  bool planned_row = false;
   if (listed) {
     head = head_l;
     seq = seq_l;
@@ -383,12 +390,14 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     const bool no_plan = ((unsigned)stamp.x != a.plan_tag) | ((unsigned)stamp.y != ~a.plan_tag);  // not a plan for these sizes
     const bool empty_slot = (unsigned)e.x >= (unsigned)a.num_seqs;                                  // -1
     if (no_plan | empty_slot) {
-      if (no_plan) poison_output_row<E, D>(a);
+      if (no_plan) poison_output_row<E, D>(a, row_id);
       return;
     }
     head = (int)hd;
     seq = e.x;
     ctx = e.y;
+    ctx_now = a.context_lens[seq];  // looked at when the row is written: off the row's chain of dependent loads
+    planned_row = true;
   } else if (MODE != kModeParts && a.plain_order) {
     // Few rows (all resident at once): heads fastest, so that every XCD gets an
     // eighth of every sequence's heads whatever the lengths are.
@@ -758,7 +767,8 @@ __global__ void __launch_bounds__(NW * 64, (decode_min_waves<E, D, B>())) pa_dec
     }
   } else {
     T* op = static_cast<T*>(a.out) + row * D;
-    const float inv = 1.f / (L + 1e-6f);
+    // (kModeList: rows that go through the workspace, and these too, are checked by the merge kernel)
+    const float inv = (planned_row && ctx_now != ctx) ? __builtin_nanf("") : 1.f / (L + 1e-6f);
     for (int d = tid; d < D; d += NW * 64) {
       float o = 0.f;
 #pragma unroll
@@ -810,6 +820,7 @@ struct PlanArgs {
   int keep_parts_min_blocks;  // a longest context of this many blocks keeps its partitions whatever the others are (few_rows_min_blocks)
   uint32_t* items;
   unsigned* counters;
+  int* planned_lens;    // item-list form: a copy of context_lens, for the merge kernel to compare with
   int2* row_table;      // null = no balanced order
   int unit;
   int slots_per_xcd;
@@ -843,7 +854,9 @@ __global__ void __launch_bounds__(kPlanThreads) pa_decode_plan_kernel(const Plan
     unsigned long long total = 0;
     unsigned longest = 0;
     for (int seq = tid; seq < num_seqs; seq += nthreads) {
-      const unsigned nblk = (unsigned)((max(p.context_lens[seq], 0) + block_size - 1) / block_size);
+      const int len = p.context_lens[seq];
+      p.planned_lens[seq] = len;
+      const unsigned nblk = (unsigned)((max(len, 0) + block_size - 1) / block_size);
       total += nblk;
       longest = max(longest, nblk);
     }
@@ -979,9 +992,21 @@ pa_decode_merge_kernel(const DecodeArgs a, const int block_size, const int skip_
     // kModeList: the partition length is the plan kernel's, and only the partitions that exist were written.
     // No plan for these sizes in the workspace, or more listed pairs than slots: the decode kernel poisoned the output
     if (a.counters[0] != a.plan_tag || a.counters[1] * (unsigned)a.num_heads > a.list_slots) return;
+    if (a.row_table != nullptr) {  // ... or the row pass found another plan's row table and poisoned its rows
+      const int2 stamp = a.row_table[8u * (unsigned)a.slots_per_xcd];
+      if ((unsigned)stamp.x != a.plan_tag || (unsigned)stamp.y != ~a.plan_tag) return;
+    }
     const int seq = (int)(row / a.num_heads);
     const int ctx = a.context_lens[seq];
+    const int planned = a.planned_lens[seq];
     const int tokens_per_part = (int)a.counters[2] * block_size;
+    if (planned != ctx) {
+      // The plan (which partitions exist) was made from other context lengths than the ones this
+      // launch ran on — a workspace reused after context_lens changed.  Not a result: NaN.
+      T* bad = static_cast<T*>(a.out) + row * D;
+      for (int d = lane; d < D; d += 64) bad[d] = E::from_float(__builtin_nanf(""));
+      return;
+    }
     nparts = min((ctx + tokens_per_part - 1) / tokens_per_part, a.num_parts);
     if (nparts <= 1) return;  // kModeList wrote this row directly
   }
@@ -1105,6 +1130,7 @@ static int launch(const DecodeArgs& a, bool plan_ready, hipStream_t stream) {
     p.keep_parts_min_blocks = few_rows_min_blocks((int64_t)a.num_seqs * a.num_heads, D, B);
     p.items = const_cast<uint32_t*>(a.items);
     p.counters = a.counters;
+    p.planned_lens = const_cast<int*>(a.planned_lens);
     p.row_table = const_cast<int2*>(a.row_table);
     p.unit = a.unit;
     p.slots_per_xcd = a.slots_per_xcd;
@@ -1277,12 +1303,12 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
 
 // Workspace: the balanced order's row table [8][slots_per_xcd] of int2 first
 // (if any); with partitions, accumulators [rows * parts][D], then (max, sum)
-// pairs [rows * parts][2], fp32; kModeList appends the item list
-// [num_seqs * parts] and the three counters.
+// pairs [rows * parts][2], fp32; kModeList appends the context lengths the plan
+// was made from [num_seqs], the item list [num_seqs * parts] and the three counters.
 static size_t workspace_bytes_for(int64_t rows, const PartitionPlan& p, int head_size, int64_t num_seqs) {
   size_t n = p.slots_per_xcd > 0 ? ((size_t)8 * p.slots_per_xcd + 1) * sizeof(int2) : 0;  // + the stamp
   if (p.num_parts > 1) n += (size_t)rows * p.num_parts * (head_size + 2) * sizeof(float);
-  if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * p.num_parts * sizeof(uint32_t) + 3 * sizeof(unsigned);
+  if (p.num_parts > 1 && p.list) n += (size_t)num_seqs * (p.num_parts + 1) * sizeof(uint32_t) + 3 * sizeof(unsigned);
   return n;
 }
 
@@ -1340,6 +1366,7 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   a.ws_ml = nullptr;
   a.items = nullptr;
   a.counters = nullptr;
+  a.planned_lens = nullptr;
   a.list_slots = 0;
   a.q_stride = q_stride;
   a.scale_log2e = scale * 1.4426950408889634f;
@@ -1375,8 +1402,12 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   }
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
+    // Fine partitions need the sum of the context lengths to keep the reserved workgroup ids few — or so
+    // few rows that even one id per possible partition is a small grid (the few-rows rule below: 4
+    // sequences x 32 heads x 1024 tokens 20.1 -> 17.1 us through the entry points that plan per call).
+    const bool few_rows = rows * 2 <= kCUs;
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len,
-                                      total_context_len >= 0);
+                                      total_context_len >= 0 || few_rows);
     if (p.list && total_context_len >= 0) {
       // The plan kernel's rule, applied here with what the caller knows: no sequence is
       // longer than max_context_len, and the batch holds at least total / block_size blocks.
@@ -1422,6 +1453,8 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
         a.ws_ml = a.ws_acc + (size_t)rows * p.num_parts * head_size;
         if (p.list) {
           uint32_t* tail = reinterpret_cast<uint32_t*>(a.ws_ml + (size_t)rows * p.num_parts * 2);
+          a.planned_lens = reinterpret_cast<const int*>(tail);
+          tail += num_seqs;
           a.items = tail;
           a.counters = tail + (size_t)num_seqs * p.num_parts;
           // One workgroup id per (sequence, partition >= 1, head) that could exist.  A sequence of
