@@ -47,6 +47,7 @@ __global__ __launch_bounds__(512, 2) void kfrag_kernel(const unsigned char* k, f
 #pragma unroll
         for (int st = 0; st < 16; ++st) x ^= kf[st];
       }
+      asm volatile("" ::: "memory");  // the next tile's (and the next pass's) loads are not this tile's
     }
   }
   float acc = (float)(x[0] ^ x[1] ^ x[2] ^ x[3]);

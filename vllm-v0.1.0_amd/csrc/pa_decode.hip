@@ -1402,12 +1402,8 @@ static int decode_entry(void* out, const void* query, const void* key_cache, con
   }
   if (workspace != nullptr) {
     PA_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 3u) == 0, "workspace must be 4-byte aligned");
-    // Fine partitions need the sum of the context lengths to keep the reserved workgroup ids few — or so
-    // few rows that even one id per possible partition is a small grid (the few-rows rule below: 4
-    // sequences x 32 heads x 1024 tokens 20.1 -> 17.1 us through the entry points that plan per call).
-    const bool few_rows = rows * 2 <= kCUs;
     PartitionPlan p = plan_partitions(num_seqs, num_heads, head_size, block_size, max_context_len,
-                                      total_context_len >= 0 || few_rows);
+                                      total_context_len >= 0);
     if (p.list && total_context_len >= 0) {
       // The plan kernel's rule, applied here with what the caller knows: no sequence is
       // longer than max_context_len, and the batch holds at least total / block_size blocks.
