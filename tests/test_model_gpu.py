@@ -8,6 +8,7 @@ recomputes the whole sequence).  Checks logits at every step and that the
 greedy tokens agree wherever the reference's top-2 margin is not a tie."""
 from types import SimpleNamespace
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -277,3 +278,64 @@ def test_throughput_harness_serves_every_request_on_a_tiny_model(pkg):
     assert res["steps"] >= max(o for _, o in reqs)
     assert 0 < res["steps_with_prompts"] <= 40
     assert res["output_tokens_per_s"] > 0
+
+
+def _load_throughput_harness():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_throughput.py")
+    spec = importlib.util.spec_from_file_location("bench_throughput", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("model", ["tiny", "tiny-neox"])
+def test_forked_and_swapped_sequences_equal_their_independent_recompute(pkg, model):
+    """Parallel sampling (n = 3) on a cache so small that groups are preempted: a request's three sequences
+    share its prompt's blocks, the first append to a shared last block copies it (cache_ops.copy_blocks),
+    preempted groups go to pinned host memory and come back (cache_ops.swap_blocks both ways, on the cache
+    stream, fenced by the per-layer events).  Every sequence — fixed first token (the j-th most likely after
+    the prompt), greedy after — must produce the tokens that the same model produces for the same prefix as a
+    request of its own (n = 1, prompt = the request's prompt + that first token) with cache to spare: no fork,
+    no copy, no swap.  Steps at which either run's two best logits lie within 2e-4 end the comparison of that
+    sequence (float32 model; the two runs reach a position through different kernels)."""
+    mod = _load_throughput_harness()
+    rng = np.random.default_rng(5)
+    vocab = mod.MODELS[model]["vocab"]
+    # prompt lengths around block boundaries: 16 = a full last block (no copy-on-write), the others partial
+    lens = [5, 16, 23, 31, 32, 40, 47, 9, 18, 27]
+    outs = [14, 9, 21, 12, 17, 8, 11, 19, 13, 16]
+    requests = [(rng.integers(0, vocab, size=p).tolist(), o) for p, o in zip(lens, outs)]
+    over = {"weight_std": 0.25}  # logits with margins: greedy continuations are well defined
+    common = dict(model=model, seed=2, max_num_batched_tokens=200, dtype_name="float32", verbose=False,
+                  sampling="greedy_distinct", cfg_overrides=over, record_margins=True)
+    res = mod.run(requests=requests, n=3, max_num_seqs=12, num_blocks=16, num_cpu_blocks=40, **common)
+    assert res["forks"] == 2 * len(requests)
+    assert res["copy_on_write_blocks"] >= 2 * (len(requests) - 2) and res["copy_blocks_calls"] >= 1
+    assert res["swap_out_groups"] >= 1 and res["swap_in_groups"] == res["swap_out_groups"], res
+    assert res["swap_out_blocks"] >= 1 and res["swap_in_blocks"] == res["swap_out_blocks"]
+    seqs = res["sequences"]
+    assert len(seqs) == 3 * len(requests)
+    # the same prefixes as requests of their own
+    singles = []
+    for req, tokens, _ in seqs:
+        p = len(requests[req][0])
+        singles.append((tokens[:p + 1], requests[req][1] - 1))
+    ref = mod.run(requests=singles, n=1, max_num_seqs=64, num_blocks=512, num_cpu_blocks=0, **common)
+    assert ref["swap_out_groups"] == 0 and ref["copy_on_write_blocks"] == 0
+    ref_by_req = {r: (t, m) for r, t, m in ref["sequences"]}
+    compared = total = 0
+    for i, (req, tokens, margins) in enumerate(seqs):
+        p = len(requests[req][0])
+        want, want_margins = ref_by_req[i]
+        assert len(tokens) == p + requests[req][1] and len(want) == len(tokens)
+        assert want[:p + 1] == tokens[:p + 1]
+        # margins[k] belongs to token p + k of the forked run; the single run's first margin to token p + 1
+        for k in range(1, requests[req][1]):
+            total += 1
+            if margins[k] < 2e-4 or want_margins[k - 1] < 2e-4:
+                break
+            assert tokens[p + k] == want[p + k], (model, req, i, k)
+            compared += 1
+    assert compared >= 0.9 * total, f"{compared} of {total} tokens compared: too many near-ties, the test is vacuous"

@@ -359,6 +359,9 @@ def run(model="7b", num_prompts=1000, seed=0, max_num_batched_tokens=2560, max_n
             admitted.append(g)
             batched += s.get_len()
         if not admitted and not run_seqs:
+            if swap_out_map:  # everything that ran was preempted this step: move it out, then bring the oldest back
+                engine.swap_out(swap_out_map)
+                continue
             if swapped or waiting:
                 raise RuntimeError("nothing can run: the cache is too small for the next group (raise --num-blocks)")
             break

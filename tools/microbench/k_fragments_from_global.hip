@@ -45,7 +45,10 @@ __global__ __launch_bounds__(512, 2) void kfrag_kernel(const unsigned char* k, f
         for (int j = 0; j < 20; ++j) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q, q, o0, 0, 0, 0);  // the tile's V^T P^T and row-sum MFMAs
       } else {
 #pragma unroll
-        for (int st = 0; st < 16; ++st) x ^= kf[st];
+        for (int st = 0; st < 16; ++st) {
+          asm volatile("" : : "v"(kf[st]));  // the fragment has to arrive
+          x ^= kf[st];
+        }
       }
       asm volatile("" ::: "memory");  // the next tile's (and the next pass's) loads are not this tile's
     }

@@ -1194,10 +1194,18 @@ static int dispatch_head(int D, int B, const DecodeArgs& a, bool plan_ready, hip
 // letting the last partition of a row to finish combine them in the same launch (write-through
 // partials, an agent-scope ticket per row) measured 1 us SLOWER on 32 rows, the drain, the
 // ticket's round trip and the dependent reads costing more than the launch boundary saved.
+// When it pays, measured through the per-call entry point (32 heads x 128, HIP-graph replay, us per launch,
+// one workgroup per row -> uniform partitions): 96 rows x 1024 tokens 19.3 -> 14.7, 128 x 1024 20.5 -> 17.6,
+// 128 x 768 16.7 -> 14.8, 128 x 512 12.3 -> 11.8; but 160 x 1024 21.1 -> 21.1, 192 x 1024 22.0 -> 22.5,
+// 224 x 1024 23.0 -> 26.0, 256 x 512 15.3 -> 17.5, 256 x 1024 25.6 -> 28.8; and 256 x 2048 51.6 -> 48.6.  Up to
+// half as many rows as CUs the partitions are what fills the chip; beyond that every CU has a row, and a
+// second launch only pays once the rows are long.
 constexpr int kSplitTargetWorkgroups = 768;    // aim for this many workgroups
 constexpr int kSplitAlwaysRows = 64;           // always for launches of at most this many rows
-constexpr int kSplitMaxRows = 256;             // ... and up to this many rows
-constexpr int kSplitMinRowTokens = 256 * 1024; // ... when rows x longest context is at least this
+constexpr int kSplitFewRows = kCUs / 2;        // up to this many rows: when rows x longest context is at least ...
+constexpr int kSplitFewRowsMinRowTokens = 64 * 1024;
+constexpr int kSplitMaxRows = 256;             // up to this many rows: when it is at least ...
+constexpr int kSplitMinRowTokens = 512 * 1024;
 
 struct PartitionPlan {
   int num_parts;
@@ -1270,7 +1278,10 @@ static PartitionPlan plan_partitions(int num_seqs, int num_heads, int head_size,
   static const int target_wgs = tuning_int("PA_DECODE_TARGET_WGS", kSplitTargetWorkgroups);
   static const int split_rows = tuning_int("PA_DECODE_SPLIT_ROWS", kSplitMaxRows);
   static const int split_tokens = tuning_int("PA_DECODE_SPLIT_TOKENS", kSplitMinRowTokens);
-  const bool worth_it = rows <= kSplitAlwaysRows || (rows <= split_rows && (int64_t)max_context_len * rows >= split_tokens);
+  static const int few_rows_tokens = tuning_int("PA_DECODE_SPLIT_FEW_ROWS_TOKENS", kSplitFewRowsMinRowTokens);
+  const int64_t row_tokens = (int64_t)max_context_len * rows;
+  const bool worth_it = rows <= kSplitAlwaysRows || (rows <= kSplitFewRows && row_tokens >= few_rows_tokens) ||
+                        (rows <= split_rows && row_tokens >= split_tokens);
   int want = forced > 0 ? forced : (worth_it ? (int)((target_wgs + rows - 1) / rows) : 1);
   static const int list_mode = tuning_int("PA_DECODE_LIST", -1);  // tuning builds: 0 = never use the item list
   const int list_max_parts = list_max_parts_for(rows, fine);

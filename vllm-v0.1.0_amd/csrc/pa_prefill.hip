@@ -110,6 +110,13 @@ constexpr float kDeferLog2 = 5.f;
 #endif
 // K fragments in flight ahead of their MFMA: PA_PROMPT_PREFETCH, or _TIGHT where the register
 // budget is cut for more than two waves per SIMD
+#ifndef PA_PROMPT_HALF_PIPELINE
+#define PA_PROMPT_HALF_PIPELINE 0
+#endif
+// 1: a wave works through a 64-key tile as two halves of 32 keys, software-pipelined inside the
+// wave — the second half's score MFMAs are issued while the first half's weights are computed,
+// the first half's V^T P^T MFMAs while the second half's are — and skips the second half on its
+// own diagonal tile, where every key of that half lies above all of the wave's rows.
 
 template <typename X, int D, int NW>
 struct PromptGeometry {
@@ -300,6 +307,150 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     const bool more = kt + 1 < n_tiles;
     if (more) issue(kt + 1);
 
+    if constexpr (!F32 && PA_PROMPT_HALF_PIPELINE && G::MIN_WAVES == 2) {
+     if (wave_has_rows && kt * KT <= q0 + 31) {
+      const unsigned char* kimg = smem + buf * BUF;
+      const unsigned char* vimg = kimg + KBYTES;
+      constexpr int KS = D / 16;
+      const u32x4 ones = {X::kOnes, X::kOnes, X::kOnes, X::kOnes};
+      // scores of one 32-key half: KS MFMAs, the K fragments fetched kPre k-steps ahead
+      auto qk_half = [&](int kb, f32x16& acc) {
+        constexpr int kPre = KS < 4 ? KS : 4;
+        const unsigned char* krow = kimg + (32 * kb + r) * KSTR + 16 * hh;
+        u32x4 kf[KS];
+#pragma unroll
+        for (int st = 0; st < kPre; ++st) kf[st] = *(const u32x4*)(krow + st * 32);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+          if (st + kPre < KS) kf[st + kPre] = *(const u32x4*)(krow + (st + kPre) * 32);
+          const u32x4 qv = {qf[4 * st], qf[4 * st + 1], qf[4 * st + 2], qf[4 * st + 3]};
+          acc = X::mfma(kf[st], qv, acc);
+        }
+      };
+      auto mask_half = [&](int kb, f32x16& acc) {
+        if (kt * KT + 32 * kb + 31 > q0) {  // the half reaches the wave's diagonal
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kt * KT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            if (key > q0 + r) acc[i] = -INFINITY;
+          }
+        }
+      };
+      auto max_half = [&](const f32x16& acc) {
+        float mx = acc[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[i]);
+        return fmaxf(mx, other_half(mx)) * a.c;
+      };
+      // the running maximum follows lazily (see kDeferLog2); returns whether it moved
+      auto follow_max = [&](float mx) {
+        if (__builtin_amdgcn_ballot_w64(mx - m > kDeferLog2) == 0) return;
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+      };
+      // weights of a half, rounded to 16 bit: registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
+      auto weights_half = [&](const f32x16& acc, u32x4 (&pf)[2]) {
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(fmaf(acc[i], a.c, -m));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          pf[s2] = u32x4{X::pack2(p[8 * s2 + 0], p[8 * s2 + 1]), X::pack2(p[8 * s2 + 2], p[8 * s2 + 3]),
+                         X::pack2(p[8 * s2 + 4], p[8 * s2 + 5]), X::pack2(p[8 * s2 + 6], p[8 * s2 + 7])};
+      };
+      // O^T += V^T P^T of one 16-key group, and the group's row sums (ones as the A operand)
+      auto pv_group = [&](const u32x4 (&vtg)[DB][2], const u32x4& pf, f32x16& lsum) {
+        lsum = X::mfma(ones, pf, lsum);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const u32x4 vfrag = {vtg[db][0].x, vtg[db][0].y, vtg[db][1].x, vtg[db][1].y};
+          o[db] = X::mfma(vfrag, pf, o[db]);
+        }
+      };
+      f32x16 s0, s1, lsum;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s0[i] = s1[i] = lsum[i] = 0.f;
+      u32x4 vta[DB][2], vtb[DB][2];  // V^T fragments of two 16-key groups, used in turn
+      u32x4 pf0[2], pf1[2];
+      const bool second_half = kt * KT + 32 <= q0 + 31;  // wave-uniform: some key of the second half lies on or below a row of the wave
+
+      if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
+      qk_half(0, s0);
+      if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
+      mask_half(0, s0);
+      follow_max(max_half(s0));
+      if (second_half) {
+        // second half's scores under the first half's weights
+        qk_half(1, s1);
+        load_vt(vimg, 0, vta);
+        weights_half(s0, pf0);
+#if PA_PROMPT_SCHED
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 56 / KS, 0);
+        }
+#endif
+        mask_half(1, s1);
+        const float mx1 = max_half(s1);
+        if (__builtin_amdgcn_ballot_w64(mx1 - m > kDeferLog2) != 0) {
+          // rare: the maximum moves at the second half.  The first half's weights belong to the old one:
+          // they are added to O^T before it is rescaled.
+          load_vt(vimg, 1, vtb);
+          pv_group(vta, pf0[0], lsum);
+          pv_group(vtb, pf0[1], lsum);
+          l += lsum[0];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
+          follow_max(mx1);
+          weights_half(s1, pf1);
+          load_vt(vimg, 2, vta);
+          load_vt(vimg, 3, vtb);
+          pv_group(vta, pf1[0], lsum);
+          pv_group(vtb, pf1[1], lsum);
+        } else {
+          // first half's V^T P^T under the second half's weights
+          if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
+          load_vt(vimg, 1, vtb);
+          pv_group(vta, pf0[0], lsum);
+          load_vt(vimg, 2, vta);
+          pv_group(vtb, pf0[1], lsum);
+          weights_half(s1, pf1);
+#if PA_PROMPT_SCHED
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int db = 0; db < DB + 1; ++db) {
+              if (db < DB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 56 / (2 * (DB + 1)), 0);
+            }
+          }
+#endif
+          load_vt(vimg, 3, vtb);
+          pv_group(vta, pf1[0], lsum);
+          pv_group(vtb, pf1[1], lsum);
+          if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+      } else {
+        load_vt(vimg, 0, vta);
+        load_vt(vimg, 1, vtb);
+        weights_half(s0, pf0);
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
+        pv_group(vta, pf0[0], lsum);
+        pv_group(vtb, pf0[1], lsum);
+        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
+      }
+      l += lsum[0];
+     }
+    } else
     if (wave_has_rows && kt * KT <= q0 + 31) {  // wave-uniform: tiles above the diagonal are skipped
       const unsigned char* kimg = smem + buf * BUF;
       const unsigned char* vimg = kimg + KBYTES;
@@ -537,13 +688,16 @@ int launch_prompt(PromptArgs& args, int num_work, hipStream_t stream) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(PA_ERR_HIP, "prompt attention: no current device");
   bool& configured = configured_on[dev];
+  // tuning builds: extra LDS per workgroup, to keep a second workgroup off the CU
+  static const int lds_pad = tuning_int("PA_PROMPT_LDS_PAD", 0);
+  const int lds_bytes = G::LDS_BYTES + (NW == 4 ? lds_pad : 0);
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_prompt_kernel<X, D, NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) return fail(PA_ERR_HIP, "prompt attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  pa_prompt_kernel<X, D, NW><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(G::THREADS), G::LDS_BYTES, stream>>>(args);
+  pa_prompt_kernel<X, D, NW><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(G::THREADS), lds_bytes, stream>>>(args);
   PA_CHECK_LAUNCH("pa_prompt_kernel");
   return PA_OK;
 }
