@@ -23,10 +23,14 @@ with open(stats) as f, open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), 
     for line in f:
         if line.startswith('"Name"') or "pa::" in line:
             g.write(line)
-for name in ("bench.json", "bench_trace.json"):
+shutil.copy(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), os.path.join(dst, "bench_kernel_stats_latest.csv"))
+for name in ("bench.json", "bench_trace.json", "decode_isolated_bench.json", "decode_isolated_kernel_stats.csv",
+             "bench_kernel_medians.csv"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
+        if name.endswith(".csv"):  # stable names for the files the documents cite
+            shutil.copy(p, os.path.join(dst, name.replace(".csv", "_latest.csv")))
 
 out = {}
 for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
