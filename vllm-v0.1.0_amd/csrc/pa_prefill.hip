@@ -118,6 +118,19 @@ constexpr float kDeferLog2 = 5.f;
 // the first half's V^T P^T MFMAs while the second half's are — and skips the second half on its
 // own diagonal tile, where every key of that half lies above all of the wave's rows.
 
+// -DPA_PROMPT_TIMING (variant builds only): every wave adds the shader cycles it spent in each phase of
+// its tile loop to prompt_phase_cycles; pa_prompt_timing_read() returns and clears the totals.
+// Phases: 0 issue of the next tile's global loads, 1 scores, 2 mask + softmax, 3 V^T P^T, 4 commit to LDS
+// (waits for the global loads), 5 barrier, 6 wave-tiles counted, 7 prologue, 8 epilogue, 9 waves counted.
+#ifdef PA_PROMPT_TIMING
+__device__ unsigned long long prompt_phase_cycles[16];
+#define PA_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PA_T_ADD(slot, t1, t0) phase_acc[slot] += (t1) - (t0)
+#else
+#define PA_T(var)
+#define PA_T_ADD(slot, t1, t0)
+#endif
+
 template <typename X, int D, int NW>
 struct PromptGeometry {
   static constexpr int THREADS = 64 * NW;
@@ -174,6 +187,10 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what depends on the wave only stays out of the vector registers
   const int r = lane & 31, hh = lane >> 5;
+#ifdef PA_PROMPT_TIMING
+  unsigned long long phase_acc[10] = {};
+#endif
+  PA_T(t_start);
   const unsigned wi = blockIdx.x / (unsigned)a.num_heads;
   const int head = (int)(blockIdx.x - wi * (unsigned)a.num_heads);
   const uint32_t item = a.work[wi];
@@ -302,10 +319,15 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   commit(0, 0);
   __syncthreads();
 
+  PA_T(t_loop);
+  PA_T_ADD(7, t_loop, t_start);
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1;
     const bool more = kt + 1 < n_tiles;
+    PA_T(t0);
     if (more) issue(kt + 1);
+    PA_T(t1);
+    PA_T_ADD(0, t1, t0);
 
     if constexpr (!F32 && PA_PROMPT_HALF_PIPELINE && G::MIN_WAVES == 2) {
      if (wave_has_rows && kt * KT <= q0 + 31) {
@@ -505,6 +527,8 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
       }
 
+      PA_T(t2);
+      PA_T_ADD(1, t2, t1);
       // causal mask on the tiles that reach the diagonal (this also hides the
       // zero rows staged past the end of the prompt from every valid query)
       if (kt * KT + KT - 1 > q0) {
@@ -550,6 +574,8 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         }
       if constexpr (F32) l = l * alpha + psum;  // per-lane partial sum: lanes l and l+32 are added at the end
 
+      PA_T(t3);
+      PA_T_ADD(2, t3, t2);
       // O^T[d][q] += V^T[d][key] P^T[key][q]
       if constexpr (F32) {
 #pragma unroll
@@ -616,11 +642,25 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
         if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
         l = l * alpha + lsum[0];
       }
+#ifdef PA_PROMPT_TIMING
+      asm volatile("s_nop 0" : : "v"(o[0][0]));  // the last MFMA's result has to be there: the phase ends with it
+#endif
+      PA_T(t4);
+      PA_T_ADD(3, t4, t3);
+#ifdef PA_PROMPT_TIMING
+      phase_acc[6] += 1;
+#endif
     }
 
+    PA_T(t5);
     if (more) commit(buf ^ 1, kt + 1);
+    PA_T(t6);
+    PA_T_ADD(4, t6, t5);
     __syncthreads();
+    PA_T(t7);
+    PA_T_ADD(5, t7, t6);
   }
+  PA_T(t_epi);
 
   // ---- epilogue --------------------------------------------------------------
   if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
@@ -677,6 +717,15 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
       }
     }
   }
+#ifdef PA_PROMPT_TIMING
+  {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    phase_acc[8] += t_end - t_epi;
+    phase_acc[9] += 1;
+    if (lane == 0)
+      for (int i = 0; i < 10; ++i) atomicAdd(&prompt_phase_cycles[i], phase_acc[i]);
+  }
+#endif
 }
 
 // ---- host side -----------------------------------------------------------------
@@ -737,6 +786,14 @@ int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
 }
 
 }  // namespace
+
+#ifdef PA_PROMPT_TIMING
+extern "C" int pa_prompt_timing_read(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(prompt_phase_cycles), sizeof(prompt_phase_cycles)) != hipSuccess) return 1;
+  unsigned long long zero[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(prompt_phase_cycles), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const void* key, const void* value,
                                            const int32_t* cu_seqlens, int num_seqs, int num_heads, int head_size,
