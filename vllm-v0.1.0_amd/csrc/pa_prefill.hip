@@ -123,7 +123,8 @@ constexpr float kDeferLog2 = 5.f;
 // Phases: 0 issue of the next tile's global loads, 1 scores, 2 mask + softmax, 3 V^T P^T, 4 commit to LDS
 // (waits for the global loads), 5 barrier, 6 wave-tiles counted, 7 prologue, 8 epilogue, 9 waves counted.
 #ifdef PA_PROMPT_TIMING
-__device__ unsigned long long prompt_phase_cycles[16];
+constexpr int kTimingWaves = 32768;  // waves of one launch that find a slot of their own (the rest are not recorded)
+__device__ unsigned long long prompt_phase_cycles[kTimingWaves][10];
 #define PA_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PA_T_ADD(slot, t1, t0) phase_acc[slot] += (t1) - (t0)
 #else
@@ -170,6 +171,18 @@ struct PromptGeometry {
   // between its MFMAs instead of delaying them (+1 % on long prompts; nothing at 4 waves).
   static constexpr bool CLUSTER_PRIO = PA_PROMPT_CLUSTER_PRIO && NW == 8 && !F32;
   static constexpr int MIN_WAVES = (!F32 && D == 64 && NW == 8) ? 4 : 2;
+  // Tiles whose global loads are in flight ahead of the tile being computed: two at head size 128 with 8 waves
+  // (a second set of staging registers: 245 in all, no spill), one elsewhere.  Measured, bf16, 32 heads: 16k prompt
+  // +2.8 %, 8 x 2048 +2.7 %, 4 x 4096 +1.1 %, short prompts unchanged; head size 96 mixed (16k +1.4 %, 8 x 2048 -3 %),
+  // so it stays at one there.  A per-phase cycle count of the loop (tools/prompt_phase_cycles.py) shows why the gain
+  // is small: the ~500 cycles a wave spends in commit() per tile are not the wait for its loads — they stay with
+  // two tiles in flight — but the tile's 32 KiB going through the CU's 16-byte LDS store path (~79 bytes per
+  // clock) with all eight waves storing at once.  Committing earlier, under the softmax phase, only moved that
+  // time in front of the next LDS reads (16k prompt -1.4 %, 4 x 4096 -4 %, head size 96 -5 ... -8 %): not kept.
+#ifndef PA_PROMPT_TILES_AHEAD
+#define PA_PROMPT_TILES_AHEAD 2
+#endif
+  static constexpr int TILES_AHEAD = (PA_PROMPT_TILES_AHEAD == 2 && !F32 && D == 128 && NW == 8) ? 2 : 1;
   static_assert(KBYTES % 16 == 0 && VSTR % 16 == 0, "images must keep 16-byte alignment");
 };
 
@@ -233,7 +246,9 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   // ---- K/V staging: global -> registers -> LDS ------------------------------
   const unsigned char* kbase = (const unsigned char*)a.k + (int64_t)head * D * ES;
   const unsigned char* vbase = (const unsigned char*)a.v + (int64_t)head * D * ES;
+  constexpr int AHEAD = G::TILES_AHEAD;
   u32x4 kreg[NCH], vreg[NCH];
+  [[maybe_unused]] u32x4 kreg2[AHEAD == 2 ? NCH : 1], vreg2[AHEAD == 2 ? NCH : 1];  // the second tile in flight
   // Loads never branch on a lane: in the prompt's last tile, rows past its end
   // (and the idle lanes of a partial chunk pass) re-read the last row, and
   // commit() replaces what they fetched by zeros.  Everywhere else a thread's
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   // of them and the rest of the address arithmetic is scalar.
   const uint32_t lane_off_k = (uint32_t)((tid / CPR) * a.k_stride * ES + (tid % CPR) * 16);
   const uint32_t lane_off_v = (uint32_t)((tid / CPR) * a.v_stride * ES + (tid % CPR) * 16);
-  auto issue = [&](int kt) {
+  auto issue = [&](auto& kreg, auto& vreg, int kt) {
     if (G::UNIFORM_ROWS && kt * KT + KT <= n) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
       }
     }
   };
-  auto commit = [&](int buf, int kt) {
+  auto commit = [&](auto& kreg, auto& vreg, int buf, int kt) {
     unsigned char* kimg = smem + buf * BUF;
     unsigned char* vimg = kimg + KBYTES;
     const bool tail = kt * KT + KT > n;  // workgroup-uniform
@@ -315,17 +330,18 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     }
   };
 
-  issue(0);
-  commit(0, 0);
+  issue(kreg, vreg, 0);
+  commit(kreg, vreg, 0, 0);
   __syncthreads();
 
   PA_T(t_loop);
   PA_T_ADD(7, t_loop, t_start);
-  for (int kt = 0; kt < n_tiles; ++kt) {
+  // One tile: issue the loads of tile kt + AHEAD into (ki, vi), compute tile kt, commit tile kt + 1 from (kc, vc).
+  auto tile_step = [&](int kt, auto& ki, auto& vi, auto& kc, auto& vc) {
     const int buf = kt & 1;
     const bool more = kt + 1 < n_tiles;
     PA_T(t0);
-    if (more) issue(kt + 1);
+    if (kt + AHEAD < n_tiles) issue(ki, vi, kt + AHEAD);
     PA_T(t1);
     PA_T_ADD(0, t1, t0);
 
@@ -653,12 +669,22 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     }
 
     PA_T(t5);
-    if (more) commit(buf ^ 1, kt + 1);
+    if (more) commit(kc, vc, buf ^ 1, kt + 1);
     PA_T(t6);
     PA_T_ADD(4, t6, t5);
     __syncthreads();
     PA_T(t7);
     PA_T_ADD(5, t7, t6);
+  };
+  if constexpr (AHEAD == 2) {
+    // tile 1 goes into the first set, which the prologue has just emptied; from then on the sets alternate
+    if (n_tiles > 1) issue(kreg, vreg, 1);
+    for (int kt = 0; kt < n_tiles; kt += 2) {
+      tile_step(kt, kreg2, vreg2, kreg, vreg);
+      if (kt + 1 < n_tiles) tile_step(kt + 1, kreg, vreg, kreg2, vreg2);
+    }
+  } else {
+    for (int kt = 0; kt < n_tiles; ++kt) tile_step(kt, kreg, vreg, kreg, vreg);
   }
   PA_T(t_epi);
 
@@ -722,8 +748,9 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     phase_acc[8] += t_end - t_epi;
     phase_acc[9] += 1;
-    if (lane == 0)
-      for (int i = 0; i < 10; ++i) atomicAdd(&prompt_phase_cycles[i], phase_acc[i]);
+    const unsigned slot = blockIdx.x * (unsigned)NW + (unsigned)wave;  // a slot per wave: no atomics, which would serialise
+    if (lane == 0 && slot < (unsigned)kTimingWaves)
+      for (int i = 0; i < 10; ++i) prompt_phase_cycles[slot][i] = phase_acc[i];
   }
 #endif
 }
@@ -789,9 +816,14 @@ int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
 
 #ifdef PA_PROMPT_TIMING
 extern "C" int pa_prompt_timing_read(unsigned long long* out16) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(prompt_phase_cycles), sizeof(prompt_phase_cycles)) != hipSuccess) return 1;
-  unsigned long long zero[16] = {};
-  return hipMemcpyToSymbol(HIP_SYMBOL(prompt_phase_cycles), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
+  static std::vector<unsigned long long> host((size_t)kTimingWaves * 10);
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(prompt_phase_cycles), host.size() * 8) != hipSuccess) return 1;
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  for (int w = 0; w < kTimingWaves; ++w)
+    for (int i = 0; i < 10; ++i) out16[i] += host[(size_t)w * 10 + i];
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(prompt_phase_cycles)) != hipSuccess) return 1;
+  return hipMemset(dev, 0, host.size() * 8) == hipSuccess ? 0 : 1;
 }
 #endif
 
