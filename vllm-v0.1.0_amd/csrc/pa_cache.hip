@@ -137,6 +137,13 @@ pa_token_cache_kernel(char* __restrict__ key, char* __restrict__ value, char* __
 // The first pass is split in two — load_first() / finish() — so that a kernel can put the loads in
 // flight as soon as it knows the block, and do whatever else it has to wait for (the scan of
 // slot_mapping for a second token in the block, the key rows, a rotation) under them.
+// Build-time knobs for A/B runs: cache policy of the tile's loads and stores (1 = non-temporal).
+#ifndef PA_CACHE_TILE_LOAD_NT
+#define PA_CACHE_TILE_LOAD_NT 1
+#endif
+#ifndef PA_CACHE_TILE_STORE_NT
+#define PA_CACHE_TILE_STORE_NT 1
+#endif
 template <int ES, int U>
 struct ValueTileUpdate {
   typedef typename Word<ES>::type elem_t;
@@ -150,7 +157,11 @@ struct ValueTileUpdate {
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int ic = min(i0 + u * (int)blockDim.x, hi - 1);
+#if PA_CACHE_TILE_LOAD_NT
       v[u] = __builtin_nontemporal_load(tile + ic);
+#else
+      v[u] = tile[ic];
+#endif
       nv[u] = new_row[ic / vpr];
     }
   }
@@ -168,7 +179,11 @@ struct ValueTileUpdate {
           v[u][w] = (v[u][w] & ~(0xffffu << sh)) | ((uint32_t)nv[u] << sh);
         }
       }
+#if PA_CACHE_TILE_STORE_NT
       __builtin_nontemporal_store(v[u], tile + i);
+#else
+      tile[i] = v[u];
+#endif
     }
   }
   // lo < hi is the caller's business (an empty slice loads nothing it may not: index hi - 1 >= lo)
