@@ -42,3 +42,18 @@ python -u bench.py --roofline-only                  | tee gpurun_out/bench_roofl
 #   registers / spills / scratch of every kernel of a source file: python tools/kernel_resources.py vllm-v0.1.0_amd/csrc/pa_prefill.hip
 #   PMC passes over the prompt kernel (profiles/r02zz_prompt_pmc_cycles.txt):
 #   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/p1 -- python3 tools/prof_prompt.py bfloat16 1 16384
+# Third batch of measurements:
+bash tools/profile_round.sh r03x                                                                # the four rocprofv3 passes + summaries (profiles/r03a_*, *_latest)
+bash tools/run_exp_cache_append.sh                  | tee gpurun_out/cache_append_shape.log     # profiles/r03_cache_append_shape.txt
+bash tools/run_exp_cache_policy.sh                  | tee gpurun_out/cache_tile_policy.log      # profiles/r03_cache_tile_policy.txt (variant builds ld0st1, ld1st0, ld0st0)
+python -u tools/sweep_small_batch.py                | tee gpurun_out/small_batch.log            # reference signature against the shared plan, batch 1-16
+bash tools/run_exp_small_batch_forms.sh             | tee gpurun_out/small_batch_forms.log      # profiles/r03_small_batch_forms.txt
+python -u tools/k_fragments_from_global.py          | tee gpurun_out/k_fragments.log            # profiles/r03_k_fragments_from_global_microbench.txt
+bash tools/run_exp_prompt_occupancy.sh              | tee gpurun_out/prompt_occupancy.log       # profiles/r03_prompt_one_workgroup_per_cu_experiment.txt
+python -u tools/prompt_phase_cycles.py              | tee gpurun_out/prompt_phase_cycles.log    # profiles/r03_prompt_phase_cycles.txt (variant build `timing`: -DPA_PROMPT_TIMING)
+python -u tools/ab_prompt.py --libs default,ahead1  | tee gpurun_out/prompt_tiles_ahead.log     # profiles/r03_prompt_tiles_ahead_experiment.txt (variant -DPA_PROMPT_TILES_AHEAD=1)
+python -u tools/ab_prompt.py --libs default --dtype float32 | tee gpurun_out/prompt_fp32.log    # profiles/r03_prompt_fp32_long_shapes.txt
+python -u tools/bench_throughput.py --model 13b-tp2 --json gpurun_out/throughput_13b_tp2.json   # profiles/r03_throughput_llama13b_tp2_shard.json
+python -u tools/bench_throughput.py --model neox20b-tp4 --n 3 --num-prompts 600 --num-blocks 9000 --num-cpu-blocks 3000 --json gpurun_out/throughput_neox_n3.json                                  # ..._n3_no_preemption.json
+python -u tools/bench_throughput.py --model neox20b-tp4 --n 3 --num-prompts 600 --num-blocks 3500 --num-cpu-blocks 3000 --json gpurun_out/throughput_neox_swap.json  # ..._n3_swapping.json
+python -u tests/soak_randomized.py                  > gpurun_out/soak.log                       # profiles/r03_soak_randomized.txt
