@@ -508,8 +508,12 @@ def prompt_measurement(torch, attention_ops, device, H, D):
         out = torch.empty(T, H, D, dtype=torch.bfloat16, device=device)
         us = graph_time_us(torch, lambda i: attention_ops.multi_query_kv_attention(out, q, k, v, lens, D ** -0.5), 5)
         flops = 4 * H * D * sum(n * (n + 1) // 2 for n in lens)
+        # q, k, v read once and out written once: at short prompts that, not the MFMA pipe, is the lower bound
+        nbytes = 4 * T * H * D * 2
+        floor_us = max(flops / MFMA_PEAK_TFLOPS_16BIT / 1e6, nbytes / HBM_PEAK_GBPS / 1e3)
         res["shapes"].append({"prompts": f"{len(lens)} x {lens[0]}", "tokens": T, "us_per_launch": us, "flops": flops,
-                              "achieved": flops / us / 1e6, "frac": flops / us / 1e6 / MFMA_PEAK_TFLOPS_16BIT})
+                              "achieved": flops / us / 1e6, "frac": flops / us / 1e6 / MFMA_PEAK_TFLOPS_16BIT,
+                              "hbm_bytes": nbytes, "floor_us": floor_us, "frac_of_floor": floor_us / us})
         del qkv, out
     return res
 
