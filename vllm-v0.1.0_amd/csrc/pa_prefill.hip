@@ -678,6 +678,9 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   };
   if constexpr (AHEAD == 2) {
     // tile 1 goes into the first set, which the prologue has just emptied; from then on the sets alternate
+    // (sending tile 1's loads out with tile 0's, before the first commit, was measured: +2.8 % on 4 x 4096 but
+    // -1 ... -3 % on 512- to 2048-token prompts, whose rounds of workgroups start together and are bound by the
+    // bandwidth of that first burst, not by its latency)
     if (n_tiles > 1) issue(kreg, vreg, 1);
     for (int kt = 0; kt < n_tiles; kt += 2) {
       tile_step(kt, kreg2, vreg2, kreg, vreg);
@@ -812,6 +815,49 @@ int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
   return big_blocks * num_heads >= 4 * 256 ? 8 : 4;
 }
 
+// Heaviest-first alone starts a chip-full of equally long workgroups together whenever the batch
+// holds that many (8 prompts x 32 heads: 256 per query-block level), and then every round ends at
+// once and the next one begins with all its workgroups fetching their queries and first tiles in
+// the same microseconds.  With more than two rounds of work, the first round is instead dealt from
+// evenly spaced places of the sorted list, so that its workgroups end at different times and the
+// rest (still heaviest first) start one by one.
+#ifndef PA_PROMPT_STAGGER
+#define PA_PROMPT_STAGGER 1
+#endif
+void stagger_first_round(std::vector<uint32_t>& work, int num_heads, int waves, int head_size) {
+  static const int mode = tuning_int("PA_PROMPT_STAGGER", PA_PROMPT_STAGGER);
+  if (mode == 0) return;
+  constexpr int kChipCUs = 256;
+  // Only where a workgroup has its CU to itself (8 waves, except at head size 64 with its 128 registers):
+  // two workgroups per CU overlap one's start with the other's loop anyway, and there the staggered order
+  // only loses the heaviest-first balance (head size 64, 12 heads, 64 x 512: 12 % slower staggered).
+  if (waves != 8 || head_size == 64) return;
+  const int slots = kChipCUs;
+  const size_t first = (size_t)std::max(1, slots / num_heads);  // work items of the first round
+  if (work.size() <= 2 * first) return;  // at most two rounds: nothing to stagger against
+  // A first round that already holds several different lengths (one or two long prompts: every query block
+  // is a level of its own or shared by two) ends staggered by itself, and heaviest-first is then the better
+  // order (measured, bf16, 32 heads x 128: 1 x 16384 and 2 x 8192 2 % slower staggered; 4 x 4096 +1 ... 2.5 %,
+  // 8 x 2048 +2 ... 5 %, 16 x 1024 +5 ... 7 %, 32 x 512 +4 %).
+  size_t levels = 1;
+  for (size_t i = 1; i < first; ++i) levels += (work[i] & 0xffffu) != (work[i - 1] & 0xffffu);
+  if (levels * 4 > first) return;
+  std::vector<uint32_t> head_part, rest;
+  std::vector<char> taken(work.size(), 0);
+  // mode 1: spaced over the whole list; 2: over its heaviest three quarters; 3: over its heavier half
+  // (the lightest items stay at the end, where they even out the finish)
+  const size_t span = mode == 2 ? work.size() * 3 / 4 : mode == 3 ? work.size() / 2 : work.size();
+  for (size_t i = 0; i < first; ++i) {
+    const size_t j = i * span / first;
+    taken[j] = 1;
+    head_part.push_back(work[j]);
+  }
+  for (size_t j = 0; j < work.size(); ++j)
+    if (!taken[j]) rest.push_back(work[j]);
+  work = head_part;
+  work.insert(work.end(), rest.begin(), rest.end());
+}
+
 }  // namespace
 
 #ifdef PA_PROMPT_TIMING
@@ -886,6 +932,7 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
     }
     // query blocks far down a prompt see the most keys: start them first
     std::stable_sort(work.begin(), work.end(), [](uint32_t x, uint32_t y) { return (x & 0xffffu) > (y & 0xffffu); });
+    stagger_first_round(work, num_heads, waves, head_size);
     for (size_t w0 = 0; w0 < work.size(); w0 += kMaxWork) {
       const int nw = (int)std::min<size_t>(kMaxWork, work.size() - w0);
       std::copy(work.begin() + w0, work.begin() + w0 + nw, args.work);
