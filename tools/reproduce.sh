@@ -57,3 +57,6 @@ python -u tools/bench_throughput.py --model 13b-tp2 --json gpurun_out/throughput
 python -u tools/bench_throughput.py --model neox20b-tp4 --n 3 --num-prompts 600 --num-blocks 9000 --num-cpu-blocks 3000 --json gpurun_out/throughput_neox_n3.json                                  # ..._n3_no_preemption.json
 python -u tools/bench_throughput.py --model neox20b-tp4 --n 3 --num-prompts 600 --num-blocks 3500 --num-cpu-blocks 3000 --json gpurun_out/throughput_neox_swap.json  # ..._n3_swapping.json
 python -u tests/soak_randomized.py                  > gpurun_out/soak.log                       # profiles/r03_soak_randomized.txt
+bash tools/pmc_prompt.sh gpurun_out/pmc_prompt      | tee gpurun_out/pmc_prompt.log             # profiles/r03z_prompt_pmc_cycles.txt
+#   work order and several-units-per-workgroup A/B (variant builds: -DPA_PROMPT_STAGGER=0, -DPA_PROMPT_PERSISTENT=1):
+python -u tools/ab_prompt.py --libs default,nostagger,persist --shapes 1x16384,4x4096,8x2048,16x1024,32x512  # profiles/r03_prompt_work_order.txt, r03_prompt_persistent_units_experiment.txt

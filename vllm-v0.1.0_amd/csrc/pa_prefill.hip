@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "pa_common.h"
@@ -42,6 +43,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kMaxSeqs = 256;   // prompts per launch (table rides in the kernel arguments)
 constexpr int kMaxWork = 512;   // (prompt, query block) items per launch
+constexpr int kChipCUs = 256;
 
 struct PromptArgs {
   void* out;
@@ -52,7 +54,7 @@ struct PromptArgs {
   float c;                               // |scale| * log2(e)
   int q_mode;                            // 0: q as stored, 1: -q (scale < 0), 2: q = 0 (scale == 0)
   int num_heads;
-  int pad_;
+  int num_units;                         // (work item, head) pairs of this launch
   int32_t cu[kMaxSeqs + 1];              // first token of each prompt of this launch
   uint32_t work[kMaxWork];               // (prompt << 16) | query block, heaviest first
 };
@@ -110,13 +112,18 @@ constexpr float kDeferLog2 = 5.f;
 #endif
 // K fragments in flight ahead of their MFMA: PA_PROMPT_PREFETCH, or _TIGHT where the register
 // budget is cut for more than two waves per SIMD
-#ifndef PA_PROMPT_HALF_PIPELINE
-#define PA_PROMPT_HALF_PIPELINE 0
+
+#ifndef PA_PROMPT_PERSISTENT
+#define PA_PROMPT_PERSISTENT 0
 #endif
-// 1: a wave works through a 64-key tile as two halves of 32 keys, software-pipelined inside the
-// wave — the second half's score MFMAs are issued while the first half's weights are computed,
-// the first half's V^T P^T MFMAs while the second half's are — and skips the second half on its
-// own diagonal tile, where every key of that half lies above all of the wave's rows.
+// 1 (variant builds): where a workgroup has its CU to itself (8 waves, 16 bit, head size above 64) the
+// launch is one workgroup per CU, each working through several (work item, head) units; the K/V tiles of
+// all its units form one stream, so the first tiles of the next unit are staged under the last tiles of
+// the current one and the next queries are fetched under the current unit's epilogue.  Measured against
+// one workgroup per unit (bf16, 32 heads x 128): 32 x 512 +9 %, 16 x 1024 +1.6 %, 8 x 2048 +0.7 %,
+// 4 x 4096 -1.2 %, one 16k prompt 0: a unit switch still costs ~8.7 k cycles per wave (the wait for the
+// queries is the larger part), against ~12 k for a workgroup's start and end, and all eight waves of the
+// CU spend them together.  Not the shipped form.
 
 // -DPA_PROMPT_TIMING (variant builds only): every wave adds the shader cycles it spent in each phase of
 // its tile loop to prompt_phase_cycles; pa_prompt_timing_read() returns and clears the totals.
@@ -156,7 +163,12 @@ struct PromptGeometry {
   // they leave as whole rows.
   static constexpr int OSTR = D * 2 + 16;
   static constexpr int OUT_BYTES = F32 ? 0 : NW * 32 * OSTR;
-  static constexpr int LDS_BYTES = 2 * BUF > OUT_BYTES ? 2 * BUF : OUT_BYTES;
+  // Several units per workgroup: the strips cannot share memory with the images, which already hold
+  // the next unit's first tile when a unit's rows leave.
+  static constexpr bool PERSIST = PA_PROMPT_PERSISTENT && !F32 && NW == 8 && D != 64;
+  static constexpr int STRIP_BASE = PERSIST ? 2 * BUF : 0;
+  static constexpr int LDS_BYTES = PERSIST ? 2 * BUF + OUT_BYTES : (2 * BUF > OUT_BYTES ? 2 * BUF : OUT_BYTES);
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
   static constexpr int CPR = D * ES / 16;    // 16-byte chunks per row
   static constexpr int TOTAL = KT * CPR;
   static constexpr int NCH = (TOTAL + THREADS - 1) / THREADS;
@@ -204,15 +216,56 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   unsigned long long phase_acc[10] = {};
 #endif
   PA_T(t_start);
-  const unsigned wi = blockIdx.x / (unsigned)a.num_heads;
-  const int head = (int)(blockIdx.x - wi * (unsigned)a.num_heads);
-  const uint32_t item = a.work[wi];
-  const int seq = (int)(item >> 16), qb = (int)(item & 0xffffu);
-  const int64_t t0 = a.cu[seq];
-  const int n = a.cu[seq + 1] - a.cu[seq];
-  const int q0 = qb * kQBlock + wave * 32;  // this wave's first query row (inside the prompt)
-  const int n_tiles = (min(n, qb * kQBlock + kQBlock) + KT - 1) / KT;
-  const bool wave_has_rows = q0 < n;
+  // A unit = one (work item, head) pair: kQBlock query rows of one head of one prompt.  Unit u of the
+  // launch is work item u / num_heads, head u % num_heads (heaviest items first).  A persistent
+  // workgroup takes one unit of every round of gridDim.x units, from alternating ends, which evens
+  // out the sums; otherwise the workgroup is its one unit.  Everything here is workgroup-uniform.
+  struct Unit {
+    int valid, head, n, n_tiles, qb;
+    int64_t t0;
+  };
+  auto load_unit = [&](int j) {
+    int u;
+    if constexpr (G::PERSIST) {
+      u = j * (int)gridDim.x + ((j & 1) ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x);
+    } else {
+      u = j == 0 ? (int)blockIdx.x : a.num_units;
+    }
+    Unit it;
+    it.valid = u < a.num_units;
+    if (!it.valid) u = 0;  // table reads stay in range
+    const unsigned wi = (unsigned)u / (unsigned)a.num_heads;
+    it.head = (int)((unsigned)u - wi * (unsigned)a.num_heads);
+    const uint32_t item = a.work[wi];
+    const int seq = (int)(item >> 16);
+    it.qb = (int)(item & 0xffffu);
+    it.t0 = a.cu[seq];
+    it.n = a.cu[seq + 1] - a.cu[seq];
+    it.n_tiles = (min(it.n, it.qb * kQBlock + kQBlock) + KT - 1) / KT;
+    return it;
+  };
+  // a place in the workgroup's stream of K/V tiles: tile kt of its unit number j
+  struct Cursor {
+    Unit u;
+    int j, kt;
+    const unsigned char* kp;  // first key / value row of the tile, this head's columns: carried from tile to
+    const unsigned char* vp;  // tile by one scalar addition each, so that issuing a tile costs no multiplications
+  };
+  const int64_t k_row_bytes = a.k_stride * ES, v_row_bytes = a.v_stride * ES;  // below 16 MiB (checked by the host)
+  auto first_tile = [&](Cursor& c) {
+    c.kt = 0;
+    c.kp = (const unsigned char*)a.k + c.u.t0 * k_row_bytes + (int64_t)c.u.head * D * ES;
+    c.vp = (const unsigned char*)a.v + c.u.t0 * v_row_bytes + (int64_t)c.u.head * D * ES;
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.kt == c.u.n_tiles) {
+      c.u = load_unit(++c.j);
+      first_tile(c);
+    } else {
+      c.kp += KT * k_row_bytes;
+      c.vp += KT * v_row_bytes;
+    }
+  };
 
   // Columns D..DP-1 of the V image (head size 80) are never staged: clear
   // both buffers once so the padded rows of O^T stay finite.
@@ -226,26 +279,43 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   // k-step ks.  fp32: dword ks = Q[q0 + r][hh D/2 + ks] (the summation order
   // over d is a free choice as long as K uses the same).
   uint32_t qf[NQ];
-  {
-    const bool ok = q0 + r < n && a.q_mode != 2;
+  // Inside the tile loop (several units per workgroup) the lane-dependent addresses of the query fetch and of
+  // the epilogue must not be hoisted out of it: that would hold a dozen registers over the whole loop.
+  auto opaque_lane = [&]() {
+    int ln = lane;
+    if constexpr (G::PERSIST) asm volatile("" : "+v"(ln));
+    return ln;
+  };
+  auto load_q = [&](const Unit& it) {
+    const int ln = opaque_lane();
+    const int r = ln & 31, hh = ln >> 5;
+    const int q0 = it.qb * kQBlock + wave * 32;
+    const bool ok = q0 + r < it.n && a.q_mode != 2;
     const unsigned char* qrow =
-        (const unsigned char*)a.q + ((t0 + q0 + r) * a.q_stride + (int64_t)head * D) * ES;
-    const uint32_t flip = a.q_mode == 1 ? (F32 ? 0x80000000u : 0x80008000u) : 0u;
+        (const unsigned char*)a.q + ((it.t0 + q0 + r) * a.q_stride + (int64_t)it.head * D) * ES;
 #pragma unroll
     for (int i = 0; i < NQ / 4; ++i) {
       const int byte_off = F32 ? (hh * (D / 2) + 4 * i) * 4 : (16 * i + 8 * hh) * 2;
       u32x4 v = {0, 0, 0, 0};
       if (ok) v = *(const u32x4*)(qrow + byte_off);
-      qf[4 * i + 0] = v.x ^ flip;
-      qf[4 * i + 1] = v.y ^ flip;
-      qf[4 * i + 2] = v.z ^ flip;
-      qf[4 * i + 3] = v.w ^ flip;
+      qf[4 * i + 0] = v.x;
+      qf[4 * i + 1] = v.y;
+      qf[4 * i + 2] = v.z;
+      qf[4 * i + 3] = v.w;
     }
-  }
+  };
+  // A negative scale is applied as -q (the kernel's factor is |scale|).  Kept apart from the fetch, behind a
+  // uniform branch: nothing else touches the fragments before the first MFMA, so a fetch issued before a
+  // unit's epilogue is waited for after it.
+  auto negate_q_if_asked = [&]() {
+    if (a.q_mode == 1) {
+      const uint32_t flip = F32 ? 0x80000000u : 0x80008000u;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) qf[i] ^= flip;
+    }
+  };
 
   // ---- K/V staging: global -> registers -> LDS ------------------------------
-  const unsigned char* kbase = (const unsigned char*)a.k + (int64_t)head * D * ES;
-  const unsigned char* vbase = (const unsigned char*)a.v + (int64_t)head * D * ES;
   constexpr int AHEAD = G::TILES_AHEAD;
   u32x4 kreg[NCH], vreg[NCH];
   [[maybe_unused]] u32x4 kreg2[AHEAD == 2 ? NCH : 1], vreg2[AHEAD == 2 ? NCH : 1];  // the second tile in flight
@@ -256,26 +326,26 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
   // of them and the rest of the address arithmetic is scalar.
   const uint32_t lane_off_k = (uint32_t)((tid / CPR) * a.k_stride * ES + (tid % CPR) * 16);
   const uint32_t lane_off_v = (uint32_t)((tid / CPR) * a.v_stride * ES + (tid % CPR) * 16);
-  auto issue = [&](auto& kreg, auto& vreg, int kt) {
-    if (G::UNIFORM_ROWS && kt * KT + KT <= n) {
+  auto issue = [&](auto& kreg, auto& vreg, const Cursor& c) {
+    const int rows_left = c.u.n - c.kt * KT;  // rows of the prompt from this tile's first on (at least 1)
+    if (G::UNIFORM_ROWS && rows_left >= KT) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int64_t tok = t0 + kt * KT + i * G::ROWS_PER_PASS;  // uniform
-        kreg[i] = *(const u32x4*)(kbase + tok * a.k_stride * ES + lane_off_k);
-        vreg[i] = *(const u32x4*)(vbase + tok * a.v_stride * ES + lane_off_v);
+        kreg[i] = *(const u32x4*)(c.kp + i * G::ROWS_PER_PASS * k_row_bytes + lane_off_k);
+        vreg[i] = *(const u32x4*)(c.vp + i * G::ROWS_PER_PASS * v_row_bytes + lane_off_v);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const int cidx = tid + THREADS * i;
-        const int row = min(cidx / CPR, KT - 1), ch = cidx % CPR;
-        const int64_t tok = t0 + min(kt * KT + row, n - 1);
-        kreg[i] = *(const u32x4*)(kbase + tok * a.k_stride * ES + ch * 16);
-        vreg[i] = *(const u32x4*)(vbase + tok * a.v_stride * ES + ch * 16);
+        const int row = min(min(cidx / CPR, KT - 1), rows_left - 1), ch = cidx % CPR;
+        kreg[i] = *(const u32x4*)(c.kp + (uint32_t)(row * (int)k_row_bytes + ch * 16));
+        vreg[i] = *(const u32x4*)(c.vp + (uint32_t)(row * (int)v_row_bytes + ch * 16));
       }
     }
   };
-  auto commit = [&](auto& kreg, auto& vreg, int buf, int kt) {
+  auto commit = [&](auto& kreg, auto& vreg, int buf, const Cursor& c) {
+    const int n = c.u.n, kt = c.kt;
     unsigned char* kimg = smem + buf * BUF;
     unsigned char* vimg = kimg + KBYTES;
     const bool tail = kt * KT + KT > n;  // workgroup-uniform
@@ -330,165 +400,103 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     }
   };
 
-  issue(kreg, vreg, 0);
-  commit(kreg, vreg, 0, 0);
+  // ---- a unit's rows leave -----------------------------------------------------
+  auto epilogue = [&](const Unit& it, const int q0) {
+    const int lane = opaque_lane();
+    const int r = lane & 31, hh = lane >> 5;
+    if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
+    const float inv = 1.f / l;
+    if constexpr (F32) {
+      if (q0 + r < it.n) {
+        unsigned char* orow = (unsigned char*)a.out + ((it.t0 + q0 + r) * a.num_heads + it.head) * (int64_t)D * ES;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d = 32 * db + 8 * g + 4 * hh;  // registers 4g..4g+3 = rows d..d+3 of O^T
+            if (d < D)
+              *(f32x4*)(orow + d * 4) = f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
+          }
+      }
+    } else {
+      // Registers 4g..4g+3 of a lane are rows 8g + 4hh + 0..3 of the d block: 8 bytes of the output
+      // row, the other 8 of the same 16 sit in lane l ^ 32.  Two v_permlane32_swap per pair of
+      // groups give lanes 0-31 the 16 bytes of group g and lanes 32-63 those of group g + 1.  The
+      // 16-byte pieces go to the wave's LDS strip (memory of its own where the workgroup goes on to
+      // another unit; else the K/V images', which are dead once every wave is past the last tile's
+      // barrier) and come back with LPR lanes per row: global stores of whole rows instead of 64
+      // pieces in 32 rows per instruction.
+      constexpr int OSTR = G::OSTR;
+      unsigned char* strip = smem + G::STRIP_BASE + wave * 32 * OSTR;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int g = 2 * gp;
+          const uint32_t x0 = X::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          const uint32_t x1 = X::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          const uint32_t y0 = X::pack2(o[db][4 * g + 4] * inv, o[db][4 * g + 5] * inv);
+          const uint32_t y1 = X::pack2(o[db][4 * g + 6] * inv, o[db][4 * g + 7] * inv);
+          // swap(old, src): old keeps its lanes 0-31 and takes src's lanes 0-31 into its lanes 32-63;
+          // src takes old's lanes 32-63 into its lanes 0-31 and keeps its lanes 32-63
+          const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+          const int d = 32 * db + 8 * (g + hh);
+          if (d < D) *(u32x4*)(strip + r * OSTR + d * 2) = u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
+        }
+      __builtin_amdgcn_wave_barrier();
+      constexpr int LPR = CPR <= 8 ? 8 : 16;  // lanes per output row (CPR of them store)
+      constexpr int RPI = 64 / LPR;           // rows per store instruction
+      const int chunk = lane % LPR;
+      unsigned char* obase = (unsigned char*)a.out + ((it.t0 + q0) * a.num_heads + it.head) * (int64_t)D * ES;
+#pragma unroll
+      for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + lane / LPR;
+        if (chunk < CPR && q0 + row < it.n) {
+          const u32x4 v = *(const u32x4*)(strip + row * OSTR + chunk * 16);
+          *(u32x4*)(obase + (int64_t)row * a.num_heads * D * ES + chunk * 16) = v;
+        }
+      }
+    }
+  };
+
+  // The stream of tiles: ci = the next tile to load, cc = the next tile to commit, (cur, kt) = the tile to
+  // compute.  Stream position p lives in LDS buffer p & 1.
+  Cursor ci;
+  ci.u = load_unit(0);
+  ci.j = 0;
+  first_tile(ci);
+  Cursor cc = ci;
+  Unit cur = ci.u;
+  int cur_j = 0, kt = 0;
+  int q0 = cur.qb * kQBlock + wave * 32;  // this wave's first query row (inside the prompt)
+  bool wave_has_rows = q0 < cur.n;
+  bool done = false;
+  load_q(cur);
+  negate_q_if_asked();
+  issue(kreg, vreg, ci);
+  advance(ci);
+  commit(kreg, vreg, 0, cc);
+  advance(cc);
   __syncthreads();
 
   PA_T(t_loop);
   PA_T_ADD(7, t_loop, t_start);
-  // One tile: issue the loads of tile kt + AHEAD into (ki, vi), compute tile kt, commit tile kt + 1 from (kc, vc).
-  auto tile_step = [&](int kt, auto& ki, auto& vi, auto& kc, auto& vc) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < n_tiles;
+  // One tile: issue the loads of stream position step + AHEAD into (ki, vi), compute position step, commit
+  // position step + 1 from (kc, vc); when that was the unit's last tile, send its rows out and take the next unit.
+  // The stream position's parity is a compile-time constant of each of the loop's two copies of the step, so
+  // that the buffer's place in LDS folds into the instructions' offsets.
+  auto tile_step = [&](auto parity, auto& ki, auto& vi, auto& kc, auto& vc) {
+    constexpr int buf = decltype(parity)::value;
     PA_T(t0);
-    if (kt + AHEAD < n_tiles) issue(ki, vi, kt + AHEAD);
+    if (ci.u.valid) {
+      issue(ki, vi, ci);
+      advance(ci);
+    }
     PA_T(t1);
     PA_T_ADD(0, t1, t0);
 
-    if constexpr (!F32 && PA_PROMPT_HALF_PIPELINE && G::MIN_WAVES == 2) {
-     if (wave_has_rows && kt * KT <= q0 + 31) {
-      const unsigned char* kimg = smem + buf * BUF;
-      const unsigned char* vimg = kimg + KBYTES;
-      constexpr int KS = D / 16;
-      const u32x4 ones = {X::kOnes, X::kOnes, X::kOnes, X::kOnes};
-      // scores of one 32-key half: KS MFMAs, the K fragments fetched kPre k-steps ahead
-      auto qk_half = [&](int kb, f32x16& acc) {
-        constexpr int kPre = KS < 4 ? KS : 4;
-        const unsigned char* krow = kimg + (32 * kb + r) * KSTR + 16 * hh;
-        u32x4 kf[KS];
-#pragma unroll
-        for (int st = 0; st < kPre; ++st) kf[st] = *(const u32x4*)(krow + st * 32);
-#pragma unroll
-        for (int st = 0; st < KS; ++st) {
-          if (st + kPre < KS) kf[st + kPre] = *(const u32x4*)(krow + (st + kPre) * 32);
-          const u32x4 qv = {qf[4 * st], qf[4 * st + 1], qf[4 * st + 2], qf[4 * st + 3]};
-          acc = X::mfma(kf[st], qv, acc);
-        }
-      };
-      auto mask_half = [&](int kb, f32x16& acc) {
-        if (kt * KT + 32 * kb + 31 > q0) {  // the half reaches the wave's diagonal
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = kt * KT + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            if (key > q0 + r) acc[i] = -INFINITY;
-          }
-        }
-      };
-      auto max_half = [&](const f32x16& acc) {
-        float mx = acc[0];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[i]);
-        return fmaxf(mx, other_half(mx)) * a.c;
-      };
-      // the running maximum follows lazily (see kDeferLog2); returns whether it moved
-      auto follow_max = [&](float mx) {
-        if (__builtin_amdgcn_ballot_w64(mx - m > kDeferLog2) == 0) return;
-        const float m_new = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        m = m_new;
-        l *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-      };
-      // weights of a half, rounded to 16 bit: registers 8 s2 .. 8 s2 + 7 = keys 16 s2 + {4 hh + 0..3, 8 + 4 hh + 0..3}
-      auto weights_half = [&](const f32x16& acc, u32x4 (&pf)[2]) {
-        float p[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(fmaf(acc[i], a.c, -m));
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-          pf[s2] = u32x4{X::pack2(p[8 * s2 + 0], p[8 * s2 + 1]), X::pack2(p[8 * s2 + 2], p[8 * s2 + 3]),
-                         X::pack2(p[8 * s2 + 4], p[8 * s2 + 5]), X::pack2(p[8 * s2 + 6], p[8 * s2 + 7])};
-      };
-      // O^T += V^T P^T of one 16-key group, and the group's row sums (ones as the A operand)
-      auto pv_group = [&](const u32x4 (&vtg)[DB][2], const u32x4& pf, f32x16& lsum) {
-        lsum = X::mfma(ones, pf, lsum);
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const u32x4 vfrag = {vtg[db][0].x, vtg[db][0].y, vtg[db][1].x, vtg[db][1].y};
-          o[db] = X::mfma(vfrag, pf, o[db]);
-        }
-      };
-      f32x16 s0, s1, lsum;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s0[i] = s1[i] = lsum[i] = 0.f;
-      u32x4 vta[DB][2], vtb[DB][2];  // V^T fragments of two 16-key groups, used in turn
-      u32x4 pf0[2], pf1[2];
-      const bool second_half = kt * KT + 32 <= q0 + 31;  // wave-uniform: some key of the second half lies on or below a row of the wave
-
-      if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
-      qk_half(0, s0);
-      if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
-      mask_half(0, s0);
-      follow_max(max_half(s0));
-      if (second_half) {
-        // second half's scores under the first half's weights
-        qk_half(1, s1);
-        load_vt(vimg, 0, vta);
-        weights_half(s0, pf0);
-#if PA_PROMPT_SCHED
-#pragma unroll
-        for (int st = 0; st < KS; ++st) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 56 / KS, 0);
-        }
-#endif
-        mask_half(1, s1);
-        const float mx1 = max_half(s1);
-        if (__builtin_amdgcn_ballot_w64(mx1 - m > kDeferLog2) != 0) {
-          // rare: the maximum moves at the second half.  The first half's weights belong to the old one:
-          // they are added to O^T before it is rescaled.
-          load_vt(vimg, 1, vtb);
-          pv_group(vta, pf0[0], lsum);
-          pv_group(vtb, pf0[1], lsum);
-          l += lsum[0];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
-          follow_max(mx1);
-          weights_half(s1, pf1);
-          load_vt(vimg, 2, vta);
-          load_vt(vimg, 3, vtb);
-          pv_group(vta, pf1[0], lsum);
-          pv_group(vtb, pf1[1], lsum);
-        } else {
-          // first half's V^T P^T under the second half's weights
-          if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
-          load_vt(vimg, 1, vtb);
-          pv_group(vta, pf0[0], lsum);
-          load_vt(vimg, 2, vta);
-          pv_group(vtb, pf0[1], lsum);
-          weights_half(s1, pf1);
-#if PA_PROMPT_SCHED
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-#pragma unroll
-            for (int db = 0; db < DB + 1; ++db) {
-              if (db < DB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, 56 / (2 * (DB + 1)), 0);
-            }
-          }
-#endif
-          load_vt(vimg, 3, vtb);
-          pv_group(vta, pf1[0], lsum);
-          pv_group(vtb, pf1[1], lsum);
-          if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
-        }
-      } else {
-        load_vt(vimg, 0, vta);
-        load_vt(vimg, 1, vtb);
-        weights_half(s0, pf0);
-        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(1);
-        pv_group(vta, pf0[0], lsum);
-        pv_group(vtb, pf0[1], lsum);
-        if constexpr (G::CLUSTER_PRIO) __builtin_amdgcn_s_setprio(0);
-      }
-      l += lsum[0];
-     }
-    } else
     if (wave_has_rows && kt * KT <= q0 + 31) {  // wave-uniform: tiles above the diagonal are skipped
       const unsigned char* kimg = smem + buf * BUF;
       const unsigned char* vimg = kimg + KBYTES;
@@ -669,87 +677,82 @@ __global__ __launch_bounds__(64 * NW, (PromptGeometry<X, D, NW>::MIN_WAVES)) voi
     }
 
     PA_T(t5);
-    if (more) commit(kc, vc, buf ^ 1, kt + 1);
+    if (cc.u.valid) {
+      commit(kc, vc, buf ^ 1, cc);
+      advance(cc);
+    }
     PA_T(t6);
     PA_T_ADD(4, t6, t5);
     __syncthreads();
     PA_T(t7);
     PA_T_ADD(5, t7, t6);
-  };
-  if constexpr (AHEAD == 2) {
-    // tile 1 goes into the first set, which the prologue has just emptied; from then on the sets alternate
-    // (sending tile 1's loads out with tile 0's, before the first commit, was measured: +2.8 % on 4 x 4096 but
-    // -1 ... -3 % on 512- to 2048-token prompts, whose rounds of workgroups start together and are bound by the
-    // bandwidth of that first burst, not by its latency)
-    if (n_tiles > 1) issue(kreg, vreg, 1);
-    for (int kt = 0; kt < n_tiles; kt += 2) {
-      tile_step(kt, kreg2, vreg2, kreg, vreg);
-      if (kt + 1 < n_tiles) tile_step(kt + 1, kreg, vreg, kreg2, vreg2);
-    }
-  } else {
-    for (int kt = 0; kt < n_tiles; ++kt) tile_step(kt, kreg, vreg, kreg, vreg);
-  }
-  PA_T(t_epi);
-
-  // ---- epilogue --------------------------------------------------------------
-  if constexpr (F32) l += other_half(l);  // the 16-bit path's sums already cover both halves
-  const float inv = 1.f / l;
-  if constexpr (F32) {
-    if (q0 + r < n) {
-      unsigned char* orow = (unsigned char*)a.out + ((t0 + q0 + r) * a.num_heads + head) * (int64_t)D * ES;
+    if constexpr (!G::PERSIST) {
+      done = ++kt == cur.n_tiles;  // the one unit's rows leave after the loop
+    } else if (++kt == cur.n_tiles) {
+      // The unit's last tile is done.  The next unit's queries are fetched first (the old fragments are
+      // dead), so that they arrive while this unit's rows are normalised and stored.  (Fetching them a
+      // tile earlier, right after the unit's last scores, needs a second set of registers in the
+      // compiler's hands: 366 spilled at head size 128.)
+      PA_T(t_epi);
+      const Unit old = cur;
+      const int old_q0 = q0;
+      cur = load_unit(++cur_j);
+      if (cur.valid) load_q(cur);
+      epilogue(old, old_q0);
+      if (cur.valid) negate_q_if_asked();
+      // The fetch is waited for HERE, once per unit: left pending across the loop's back edge, every tile's
+      // first MFMA would wait for all loads before it, the tile's own K/V loads included (measured: the
+      // score phase twice as long).
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) asm volatile("" : "+v"(qf[i]));
+      q0 = cur.qb * kQBlock + wave * 32;
+      wave_has_rows = cur.valid && q0 < cur.n;
+      kt = 0;
+      m = -INFINITY;
+      l = 0.f;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = 32 * db + 8 * g + 4 * hh;  // registers 4g..4g+3 = rows d..d+3 of O^T
-          if (d < D)
-            *(f32x4*)(orow + d * 4) = f32x4{o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv};
-        }
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+      done = !cur.valid;
+#ifdef PA_PROMPT_TIMING
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+      phase_acc[8] += t_end - t_epi;
+#endif
+    }
+  };
+  if constexpr (AHEAD == 2) {
+    // position 1 goes into the first set, which the prologue has just emptied; from then on the sets alternate
+    // (sending its loads out with position 0's, before the first commit, was measured: +2.8 % on 4 x 4096 but
+    // -1 ... -3 % on 512- to 2048-token prompts, whose rounds of workgroups start together and are bound by the
+    // bandwidth of that first burst, not by its latency)
+    if (ci.u.valid) {
+      issue(kreg, vreg, ci);
+      advance(ci);
+    }
+    while (true) {
+      tile_step(std::integral_constant<int, 0>{}, kreg2, vreg2, kreg, vreg);
+      if (done) break;
+      tile_step(std::integral_constant<int, 1>{}, kreg, vreg, kreg2, vreg2);
+      if (done) break;
     }
   } else {
-    // Registers 4g..4g+3 of a lane are rows 8g + 4hh + 0..3 of the d block: 8 bytes of the output
-    // row, the other 8 of the same 16 sit in lane l ^ 32.  Two v_permlane32_swap per pair of
-    // groups give lanes 0-31 the 16 bytes of group g and lanes 32-63 those of group g + 1.  The
-    // 16-byte pieces go to the wave's LDS strip (every wave is past the loop's last barrier, so
-    // the K/V images are dead) and come back with LPR lanes per row: global stores of whole
-    // rows instead of 64 pieces in 32 rows per instruction.
-    constexpr int OSTR = G::OSTR;
-    unsigned char* strip = smem + wave * 32 * OSTR;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        const int g = 2 * gp;
-        const uint32_t x0 = X::pack2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
-        const uint32_t x1 = X::pack2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-        const uint32_t y0 = X::pack2(o[db][4 * g + 4] * inv, o[db][4 * g + 5] * inv);
-        const uint32_t y1 = X::pack2(o[db][4 * g + 6] * inv, o[db][4 * g + 7] * inv);
-        // swap(old, src): old keeps its lanes 0-31 and takes src's lanes 0-31 into its lanes 32-63;
-        // src takes old's lanes 32-63 into its lanes 0-31 and keeps its lanes 32-63
-        const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-        const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-        const int d = 32 * db + 8 * (g + hh);
-        if (d < D) *(u32x4*)(strip + r * OSTR + d * 2) = u32x4{(uint32_t)s0[0], (uint32_t)s1[0], (uint32_t)s0[1], (uint32_t)s1[1]};
-      }
-    __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = CPR <= 8 ? 8 : 16;  // lanes per output row (CPR of them store)
-    constexpr int RPI = 64 / LPR;           // rows per store instruction
-    const int chunk = lane % LPR;
-    unsigned char* obase = (unsigned char*)a.out + ((t0 + q0) * a.num_heads + head) * (int64_t)D * ES;
-#pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-      const int row = i * RPI + lane / LPR;
-      if (chunk < CPR && q0 + row < n) {
-        const u32x4 v = *(const u32x4*)(strip + row * OSTR + chunk * 16);
-        *(u32x4*)(obase + (int64_t)row * a.num_heads * D * ES + chunk * 16) = v;
-      }
+    while (true) {
+      tile_step(std::integral_constant<int, 0>{}, kreg, vreg, kreg, vreg);
+      if (done) break;
+      tile_step(std::integral_constant<int, 1>{}, kreg, vreg, kreg, vreg);
+      if (done) break;
     }
+  }
+  if constexpr (!G::PERSIST) {
+    PA_T(t_epi);
+    epilogue(cur, q0);
+#ifdef PA_PROMPT_TIMING
+    phase_acc[8] += __builtin_amdgcn_s_memtime() - t_epi;
+#endif
   }
 #ifdef PA_PROMPT_TIMING
   {
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    phase_acc[8] += t_end - t_epi;
     phase_acc[9] += 1;
     const unsigned slot = blockIdx.x * (unsigned)NW + (unsigned)wave;  // a slot per wave: no atomics, which would serialise
     if (lane == 0 && slot < (unsigned)kTimingWaves)
@@ -776,7 +779,10 @@ int launch_prompt(PromptArgs& args, int num_work, hipStream_t stream) {
     if (e != hipSuccess) return fail(PA_ERR_HIP, "prompt attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
     configured = true;
   }
-  pa_prompt_kernel<X, D, NW><<<dim3((unsigned)num_work * (unsigned)args.num_heads), dim3(G::THREADS), lds_bytes, stream>>>(args);
+  args.num_units = num_work * args.num_heads;
+  // several units per workgroup: one workgroup per CU (each fills its CU), fewer for a small launch
+  const int grid = G::PERSIST ? std::min(args.num_units, kChipCUs) : args.num_units;
+  pa_prompt_kernel<X, D, NW><<<dim3((unsigned)grid), dim3(G::THREADS), lds_bytes, stream>>>(args);
   PA_CHECK_LAUNCH("pa_prompt_kernel");
   return PA_OK;
 }
@@ -824,10 +830,10 @@ int choose_waves(const int32_t* cu, int num_seqs, int num_heads) {
 #ifndef PA_PROMPT_STAGGER
 #define PA_PROMPT_STAGGER 1
 #endif
-void stagger_first_round(std::vector<uint32_t>& work, int num_heads, int waves, int head_size) {
+void stagger_first_round(std::vector<uint32_t>& work, int num_heads, int waves, int head_size, int dtype) {
+  if (PA_PROMPT_PERSISTENT && dtype != PA_DTYPE_F32) return;  // those launches deal the units to resident workgroups themselves
   static const int mode = tuning_int("PA_PROMPT_STAGGER", PA_PROMPT_STAGGER);
   if (mode == 0) return;
-  constexpr int kChipCUs = 256;
   // Only where a workgroup has its CU to itself (8 waves, except at head size 64 with its 128 registers):
   // two workgroups per CU overlap one's start with the other's loop anyway, and there the staggered order
   // only loses the heaviest-first balance (head size 64, 12 heads, 64 x 512: 12 % slower staggered).
@@ -916,7 +922,7 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
     args.q_mode = 2;
   }
   args.num_heads = num_heads;
-  args.pad_ = 0;
+  args.num_units = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
 
   const int waves = choose_waves(cu_seqlens, num_seqs, num_heads);
@@ -932,7 +938,7 @@ extern "C" int pa_multi_query_kv_attention(void* out, const void* query, const v
     }
     // query blocks far down a prompt see the most keys: start them first
     std::stable_sort(work.begin(), work.end(), [](uint32_t x, uint32_t y) { return (x & 0xffffu) > (y & 0xffffu); });
-    stagger_first_round(work, num_heads, waves, head_size);
+    stagger_first_round(work, num_heads, waves, head_size, dtype);
     for (size_t w0 = 0; w0 < work.size(); w0 += kMaxWork) {
       const int nw = (int)std::min<size_t>(kMaxWork, work.size() - w0);
       std::copy(work.begin() + w0, work.begin() + w0 + nw, args.work);
