@@ -355,3 +355,54 @@ def test_kernel_randomized_shapes_against_oracle(pkg, seed):
     bound = EPS[dtype] * (2.0 + 3.0 * np.abs(want)) + 2e-6
     err = np.abs(got - want)
     assert np.all(err <= bound), f"seed {seed} lens={lens} H={H} D={D} {dtype}: max err {err.max():.3e}"
+
+
+@pytest.mark.gpu
+def test_kernel_with_more_prompts_than_one_launch_carries(pkg):
+    """The prompt table rides in the kernel arguments, 256 prompts per launch: a batch of 300 short prompts
+    is served by two launches of one call; every prompt against torch's attention, rows past the batch untouched."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    lens = [int(x) for x in rng.integers(1, 48, size=300)]
+    T, H, D = sum(lens), 2, 64
+    g = torch.Generator(device=DEV)
+    g.manual_seed(31)
+    qkv = torch.randn(T + 3, 3, H, D, dtype=torch.float16, device=DEV, generator=g)
+    q, k, v = qkv.unbind(dim=1)
+    out = torch.full((T + 3, H, D), float("nan"), dtype=torch.float16, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(out, q, k, v, lens, D ** -0.5)
+    lo = 0
+    for n in lens:
+        o = F.scaled_dot_product_attention(q[lo:lo + n].transpose(0, 1).float(), k[lo:lo + n].transpose(0, 1).float(),
+                                           v[lo:lo + n].transpose(0, 1).float(), is_causal=True, scale=D ** -0.5)
+        assert torch.allclose(out[lo:lo + n].float(), o.transpose(0, 1), atol=3e-3, rtol=3e-3), (lo, n)
+        lo += n
+    assert torch.isnan(out[T:]).all()
+
+
+@pytest.mark.gpu
+def test_kernel_with_more_query_blocks_than_one_launch_carries(pkg):
+    """One prompt of 66 000 tokens is 516 query blocks of 128 rows, more than the 512 work items a launch
+    carries: the call splits into two launches.  Too long for a dense reference: with V = 1 every output is 1,
+    and sampled rows (first, last, both sides of the launches' seam) equal the directly computed attention."""
+    import torch
+    n, H, D = 66000, 1, 64
+    assert (n + 127) // 128 > 512 and (n + 255) // 256 * H < 1024  # 128-row workgroups, two launches
+    g = torch.Generator(device=DEV)
+    g.manual_seed(32)
+    qkv = torch.randn(n, 3, H, D, dtype=torch.bfloat16, device=DEV, generator=g)
+    q, k, v = qkv.unbind(dim=1)
+    scale = D ** -0.5
+    out = torch.full((n, H, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    pkg.attention_ops.multi_query_kv_attention(out, q, k, v, [n], scale)
+    assert torch.isfinite(out.float()).all()
+    rows = [0, 1, 127, 128, 4 * 128 - 1, 4 * 128, 4 * 128 + 1, 33000, n - 129, n - 128, n - 1]
+    kf, vf = k[:, 0].float(), v[:, 0].float()
+    for i in rows:
+        w = torch.softmax((kf[:i + 1] @ q[i, 0].float()) * scale, dim=0)
+        want = w @ vf[:i + 1]
+        assert torch.allclose(out[i, 0].float(), want, atol=2e-2, rtol=2e-2), i
+    ones = torch.ones_like(v)
+    pkg.attention_ops.multi_query_kv_attention(out, q, k, ones, [n], scale)
+    assert torch.allclose(out.float(), torch.ones(n, H, D, device=DEV), atol=2e-2)
