@@ -65,6 +65,14 @@ SHAPES = {
     "ragged512": dict(S=256, H=32, D=128, B=16, ctx=512, ragged=True),
     "bs64": dict(S=64, H=32, D=128, B=16, ctx=1024, ragged=False),
     "bs128": dict(S=128, H=32, D=128, B=16, ctx=1024, ragged=False),
+    # batches between one and three residencies of rows (768 workgroups fit the chip)
+    "bs12": dict(S=12, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs24": dict(S=24, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs32": dict(S=32, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs48": dict(S=48, H=32, D=128, B=16, ctx=1024, ragged=False),
+    "bs16_ctx4096": dict(S=16, H=32, D=128, B=16, ctx=4096, ragged=False),
+    "bs32_ctx2048": dict(S=32, H=32, D=128, B=16, ctx=2048, ragged=False),
+    "bs40_ctx4096": dict(S=40, H=32, D=128, B=16, ctx=4096, ragged=False),
 }
 
 
