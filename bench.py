@@ -113,11 +113,29 @@ def pmc_traffic(kernel_substr, args):
             table = json.load(f)
     except (OSError, ValueError):
         return None, None
+    fresh = pmc_sources_unchanged(table)
+    note = {True: "; the kernels' sources are unchanged since that pass",
+            False: "; STALE: the kernels' sources have changed since that pass",
+            None: ""}[fresh]
     for name, row in table.items():
-        if kernel_substr in name:
+        if not name.startswith("_") and kernel_substr in name:
             return row.get("hbm_traffic_bytes_per_launch"), \
-                f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass over this command, not this run)"
+                f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass over this command, not this run{note})"
     return None, None
+
+
+def pmc_sources_unchanged(table):
+    """Whether the sources of the kernels counted in the committed PMC file are the ones in this tree
+    (the file records their hashes); None if it holds no hashes or a source cannot be read."""
+    import hashlib
+    recorded = table.get("_kernel_sources_sha16")
+    if not isinstance(recorded, dict) or not recorded:
+        return None
+    try:
+        return all(hashlib.sha256(open(os.path.join(ROOT, "vllm-v0.1.0_amd", "csrc", name), "rb").read()).hexdigest()[:16] == sha
+                   for name, sha in recorded.items())
+    except OSError:
+        return None
 
 
 def parse_args(argv=None):

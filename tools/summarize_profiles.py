@@ -8,6 +8,7 @@ small summaries kept under profiles/.
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -44,7 +45,7 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for k, v in agg.items():
         out.setdefault(k, {})[counter + "_KiB_mean_per_launch"] = sum(v) / len(v)
         out[k][counter + "_launches"] = len(v)
-for k, d in out.items():
+for k, d in list(out.items()):
     f = d.get("FETCH_SIZE_KiB_mean_per_launch", 0) * 1024
     w = d.get("WRITE_SIZE_KiB_mean_per_launch", 0) * 1024
     # gfx950: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads
@@ -52,6 +53,10 @@ for k, d in out.items():
     d["read_bytes_corrected_x2"] = 2 * f
     d["write_bytes"] = w
     d["hbm_traffic_bytes_per_launch"] = 2 * f + w
+# what the counted kernels were built from: bench.py compares these with the tree it runs from and says so in its line
+out["_kernel_sources_sha16"] = {
+    name: hashlib.sha256(open(os.path.join(root, "vllm-v0.1.0_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    for name in ("pa_decode.hip", "pa_cache.hip", "pa_common.h")}
 with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as g:
     json.dump(out, g, indent=1)
 shutil.copy(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), os.path.join(dst, "pmc_hbm_traffic_latest.json"))
