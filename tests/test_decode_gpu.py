@@ -538,6 +538,38 @@ def test_decode_total_context_hint_leaves_the_item_list_out(pkg):
             assert ws.view(torch.int32)[end - 3:end].tolist()[1:] == [0, 1 << 24]
 
 
+def test_decode_equal_long_contexts_take_two_uniform_partitions(pkg):
+    """A batch between one and two residencies of rows (40 sequences x 32 heads against the 768 workgroups
+    the GPU holds) whose contexts are all (nearly) as long as the longest: with the sum of the context lengths
+    known, the launch takes two uniform partitions per row instead of the item list — no plan kernel, so the
+    tail of the workspace (where the list's items and counters would sit) stays untouched — and the result is
+    the oracle's.  A batch half of whose sequences are short keeps the list; both forms agree with the oracle."""
+    import torch
+    S, H, D, B = 40, 32, 128, 16
+    for name, ctx in (("equal", [2048 - (i % 3) * 16 for i in range(S)]), ("half_short", [2048] * (S // 2) + [300] * (S // 2))):
+        case = datagen.DecodeCase(name=name, dtype="float16", num_seqs=S, num_heads=H, head_size=D, block_size=B,
+                                  num_blocks=sum((c + B - 1) // B for c in ctx) + 5, context_lens=ctx, dist="normal",
+                                  tables="permutation", seed=97)
+        inp = datagen.make_decode_inputs(case)
+        qkv, query, kc, vc, bt, cl = helpers.decode_inputs_to_device(inp, case.dtype, "cuda:0")
+        ref = datagen.storage_to_float32(pa_oracle.single_query_cached_kv_attention(
+            inp["qkv"][:, 0], inp["key_cache"], inp["value_cache"], inp["scale"], inp["block_tables"],
+            inp["context_lens"], case.dtype), case.dtype)
+        nbytes = pkg._capi.decode_workspace_bytes(S, H, D, B, max(ctx))
+        atol, rtol = helpers.TIGHT[case.dtype]
+        ws = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device="cuda:0")
+        for ready in (False, True):
+            out = torch.full((S, H, D), float("nan"), dtype=qkv.dtype, device="cuda:0")
+            pkg._capi.single_query_cached_kv_attention_planned(out, query, kc, vc, inp["scale"], bt, cl, B, max(ctx), ws,
+                                                               ready, sum(ctx))
+            torch.cuda.synchronize()
+            helpers.assert_close(helpers.out_to_f32(out, case.dtype), ref, atol, 2 * rtol, f"{name} ready={ready}")
+        # two partitions per row: accumulators and (max, sum) pairs, nothing behind them
+        used = S * H * 2 * (D + 2)
+        assert not bool(torch.isnan(ws[:used]).any()) or name != "equal"
+        assert bool(torch.isnan(ws[used:]).all()) == (name == "equal")
+
+
 def test_decode_step_replays_from_a_hip_graph(pkg):
     """A decode step of three layers (reshape_and_cache, then attention with the
     plan shared by the layers; and the module function with the reference's

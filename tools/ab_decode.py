@@ -73,6 +73,14 @@ SHAPES = {
     "bs16_ctx4096": dict(S=16, H=32, D=128, B=16, ctx=4096, ragged=False),
     "bs32_ctx2048": dict(S=32, H=32, D=128, B=16, ctx=2048, ragged=False),
     "bs40_ctx4096": dict(S=40, H=32, D=128, B=16, ctx=4096, ragged=False),
+    "bs24_ctx4096": dict(S=24, H=32, D=128, B=16, ctx=4096, ragged=False),
+    "bs32_ctx4096": dict(S=32, H=32, D=128, B=16, ctx=4096, ragged=False),
+    "bs64_ctx4096": dict(S=64, H=32, D=128, B=16, ctx=4096, ragged=False),
+    "bs48_ctx2048": dict(S=48, H=32, D=128, B=16, ctx=2048, ragged=False),
+    "bs64_ctx2048": dict(S=64, H=32, D=128, B=16, ctx=2048, ragged=False),
+    "bs128_ctx2048": dict(S=128, H=32, D=128, B=16, ctx=2048, ragged=False),
+    "bs32_ctx8192": dict(S=32, H=32, D=128, B=16, ctx=8192, ragged=False),
+    "bs40_ctx4096_ragged": dict(S=40, H=32, D=128, B=16, ctx=4096, ragged=True),
 }
 
 

@@ -60,3 +60,4 @@ python -u tests/soak_randomized.py                  > gpurun_out/soak.log       
 bash tools/pmc_prompt.sh gpurun_out/pmc_prompt      | tee gpurun_out/pmc_prompt.log             # profiles/r03z_prompt_pmc_cycles.txt
 #   work order and several-units-per-workgroup A/B (variant builds: -DPA_PROMPT_STAGGER=0, -DPA_PROMPT_PERSISTENT=1):
 python -u tools/ab_prompt.py --libs default,nostagger,persist --shapes 1x16384,4x4096,8x2048,16x1024,32x512  # profiles/r03_prompt_work_order.txt, r03_prompt_persistent_units_experiment.txt
+bash tools/run_exp_mid_batch_parts.sh; bash tools/run_exp_long_uniform_parts.sh    # profiles/r03_mid_batch_forced_partitions.txt, r03_equal_long_contexts_two_partitions.txt
