@@ -144,7 +144,10 @@ int pa_single_query_cached_kv_attention_ws(
  * -1: with it the library can tell on the host that no sequence of a big batch
  * is long enough to need partitions, and leaves that machinery out of the
  * launch, and reserves workgroup ids only for as many partitions as that sum
- * allows.  It must be the same for all calls on one plan, and it must not be
+ * allows; it can also tell that all sequences are (nearly) as long as the
+ * longest, and then gives a mid-size batch of long contexts two uniform
+ * partitions per row instead of the item list.  It must be the same for all
+ * calls on one plan, and it must not be
  * less than the true sum: if the device finds more partitions than were
  * reserved, `out` is filled with NaN.  No counterpart in the reference.
  */
